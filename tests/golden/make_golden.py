@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+Run in a container that has the reference checkout (default /root/reference):
+
+    python tests/golden/make_golden.py [--reference /root/reference]
+
+The reference's Python never travels with this repository: this script imports
+it at generation time, feeds it seeded synthetic inputs and stores only inputs
+and outputs (.npz).  Nothing here restates reference code; the arithmetic is
+done by the imported modules (LocalConvolution.Conv2dLocal,
+AdvancedModel.DPNModel and its helpers).
+
+AdvancedModel.py imports torchvision (transforms, vgg16) at module scope, which
+is not installed here.  Neither is touched by DPNModel.forward, so an in-memory
+placeholder module is registered for the duration of the import; predict()/fit()
+pre-processing, which would need the real torchvision, is not exercised.
+
+Each case is run twice: in float32 (what the reference produces as shipped) and
+with float64 inputs (the reference code is dtype-agnostic apart from its float32
+parameters), the latter to pin index maps and formulas far below fp32 rounding.
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+from torch import nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def import_reference(path):
+    sys.path.insert(0, path)
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    if "torchvision" not in sys.modules:
+        tv = types.ModuleType("torchvision")
+        tr = types.ModuleType("torchvision.transforms")
+        md = types.ModuleType("torchvision.models")
+
+        class _Placeholder:
+            def __init__(self, *a, **k):
+                pass
+
+            def __call__(self, x):
+                raise RuntimeError("torchvision is not available in this container")
+
+        for name in ("Compose", "Resize", "ToTensor", "Normalize"):
+            setattr(tr, name, _Placeholder)
+        md.vgg16 = _Placeholder
+        tv.transforms, tv.models = tr, md
+        sys.modules.update({"torchvision": tv, "torchvision.transforms": tr, "torchvision.models": md})
+    import LocalConvolution
+    import AdvancedModel
+    return LocalConvolution, AdvancedModel
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def gen_color_distance(AM):
+    g = torch.Generator().manual_seed(101)
+    for (H, W, k) in [(5, 7, 1), (6, 5, 3), (7, 9, 4), (9, 8, 7), (4, 6, 11)]:
+        img = torch.randn(2, 3, H, W, generator=g)
+        fn = AM.DPNModel._color_distance(kernel_size=(k, k), channels=3)
+        save(f"cd_h{H}_w{W}_k{k}", img=npy(img), k=np.int64(k),
+             cd=npy(fn(img)), cd64=npy(fn(img.double())))
+
+
+def run_local(LC, x, cd, pw, cw, k, dy, dtype):
+    B, C, H, W = x.shape
+    m = LC.Conv2dLocal(H, W, C, k)
+    with torch.no_grad():
+        m.position_weight.fill_(pw)
+        m.color_weight.fill_(cw)
+    xx = x.to(dtype).clone().requires_grad_(True)
+    y = m(xx, cd.to(dtype))
+    y.backward(dy.to(dtype))
+    return (npy(y), npy(xx.grad), npy(m.position_weight.grad), npy(m.color_weight.grad),
+            npy(m.position_distances))
+
+
+def gen_local(LC):
+    g = torch.Generator().manual_seed(202)
+    cases = [  # B, C, H, W, k, pw, cw
+        (2, 2, 5, 7, 3, 0.3, -0.7),
+        (1, 3, 6, 5, 4, 0.3, -0.7),
+        (2, 19, 8, 12, 7, -0.004, -0.003),
+        (1, 21, 12, 9, 11, 0.3, -0.7),
+        (1, 4, 6, 6, 1, 0.3, -0.7),
+        (1, 5, 4, 4, 6, -0.004, -0.003),      # C*K > L: a row of the scrambled matrix is a fraction of one window set
+        (1, 21, 16, 16, 7, -0.004, -0.003),
+    ]
+    for (B, C, H, W, k, pw, cw) in cases:
+        x = torch.randn(B, C, H, W, generator=g)
+        cd = torch.rand(B, H * W, k * k, generator=g) * 3
+        dy = torch.randn(B, C, H, W, generator=g)
+        y, dx, dpw, dcw, pd = run_local(LC, x, cd, pw, cw, k, dy, torch.float32)
+        y64, dx64, dpw64, dcw64, _ = run_local(LC, x, cd, pw, cw, k, dy, torch.float64)
+        save(f"local_c{C}_h{H}_w{W}_k{k}", x=npy(x), cd=npy(cd), dy=npy(dy), k=np.int64(k),
+             pw=np.float32(pw), cw=np.float32(cw), pd=pd,
+             y=y, dx=dx, dpw=dpw, dcw=dcw, y64=y64, dx64=dx64, dpw64=dpw64, dcw64=dcw64)
+
+
+def gen_tail(AM):
+    """a5 -> a8 -> a6 -> a7 with explicit parameters (AdvancedModel.py:223-244)."""
+    g = torch.Generator().manual_seed(303)
+    B, L, M, H, W = 2, 4, 5, 10, 11
+    la = AM.LinearActivation(L, H, W)
+    conv = nn.Conv2d(L, L * M, kernel_size=(9, 9), padding=(4, 4))
+    ga = AM.LinearActivation(L * M, H, W)
+    pool = AM.BlockMinPooling(kernel_size=M, dim=1)
+    with torch.no_grad():
+        for p in (la.weight, la.bias, conv.weight, conv.bias, ga.weight, ga.bias):
+            p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+    t = torch.randn(B, L, H, W, generator=g)
+    unary = torch.randn(B, L, H, W, generator=g) * 2
+    with torch.no_grad():
+        a = la(t)
+        c = ga(conv(a))
+        smooth = pool(c)
+        out = nn.LogSoftmax(dim=1)(torch.nn.functional.log_softmax(unary, dim=1) - smooth)
+    save("tail_l4_m5", t=npy(t), unary=npy(unary), mixtures=np.int64(M),
+         la_w=npy(la.weight), la_b=npy(la.bias), conv_w=npy(conv.weight), conv_b=npy(conv.bias),
+         ga_w=npy(ga.weight), ga_b=npy(ga.bias),
+         a=npy(a), c=npy(c), smooth=npy(smooth), out=npy(out))
+
+
+class _FixedUnary(nn.Module):
+    """Stands in for the VGG-like unary stack: returns a stored synthetic unary."""
+
+    def __init__(self, unary):
+        super().__init__()
+        self.unary = unary
+
+    def forward(self, x):
+        return self.unary
+
+
+def gen_dpn(AM):
+    """DPNModel.forward(phase=2,3,4) with the unary CNN bypassed (AdvancedModel.py:198-244).
+    The model hard-codes a 50x50 window (AdvancedModel.py:135-137)."""
+    g = torch.Generator().manual_seed(404)
+    H, W, L, M = 8, 9, 4, 5
+    torch.manual_seed(404)
+    model = AM.DPNModel(H, W, num_labels=L, num_mixture_filters=M)
+    unary = torch.randn(2, L, H, W, generator=g) * 2
+    img = torch.randn(2, 3, H, W, generator=g)
+    model.unary_terms_layers = _FixedUnary(unary)
+    with torch.no_grad():
+        # local_activation_function is never initialised by the reference (torch.empty).
+        model.local_activation_function.weight.copy_(1 + 0.2 * torch.randn(1, L, H, W, generator=g))
+        model.local_activation_function.bias.copy_(0.1 * torch.randn(1, L, H, W, generator=g))
+        model.local_convolution_layer.position_weight.fill_(-0.004)
+        model.local_convolution_layer.color_weight.fill_(-0.003)
+        outs = {f"phase{p}": npy(model(img, phase=p)) for p in (2, 3, 4)}
+    sd = model.state_dict()
+    save("dpn_h8_w9_l4", img=npy(img), unary=npy(unary), mixtures=np.int64(M), k=np.int64(50),
+         pw=np.float32(-0.004), cw=np.float32(-0.003),
+         la_w=npy(sd["local_activation_function.weight"]), la_b=npy(sd["local_activation_function.bias"]),
+         conv_w=npy(sd["global_convolution_layer.weight"]), conv_b=npy(sd["global_convolution_layer.bias"]),
+         ga_w=npy(sd["global_activation_function.weight"]), ga_b=npy(sd["global_activation_function.bias"]),
+         pd=npy(sd["local_convolution_layer.position_distances"]), **outs)
+
+
+def gen_meanfield(LC, AM):
+    """K-iteration composition: every arithmetic step is an imported reference module,
+    only the for-loop is new.  compat is Conv2d(L, L, 1, bias=False) holding an LxL matrix."""
+    g = torch.Generator().manual_seed(505)
+    for (B, L, H, W, k, pw, cw, affine) in [(2, 3, 9, 11, 3, -0.004, -0.003, True),
+                                            (1, 19, 10, 14, 7, -0.004, -0.003, False),
+                                            (1, 5, 8, 8, 4, 0.05, -0.02, True)]:
+        unary = torch.randn(B, L, H, W, generator=g) * 2
+        img = torch.randn(B, 3, H, W, generator=g)
+        compat = (1 - torch.eye(L)) + 0.01 * torch.randn(L, L, generator=g)
+        la = AM.LinearActivation(L, H, W)
+        with torch.no_grad():
+            la.weight.copy_(1 + 0.2 * torch.randn(1, L, H, W, generator=g))
+            la.bias.copy_(0.1 * torch.randn(1, L, H, W, generator=g))
+        extra = {"la_w": npy(la.weight), "la_b": npy(la.bias)} if affine else {}
+        for dtype, tag in ((torch.float32, ""), (torch.float64, "64")):
+            local = LC.Conv2dLocal(H, W, L, k)
+            conv = nn.Conv2d(L, L, kernel_size=1, bias=False)
+            with torch.no_grad():
+                local.position_weight.fill_(pw)
+                local.color_weight.fill_(cw)
+                conv.weight.copy_(compat.reshape(L, L, 1, 1))
+            conv = conv.to(dtype)
+            act = la.to(dtype) if affine else (lambda t: t)
+            cdf = AM.DPNModel._color_distance(kernel_size=(k, k), channels=3)
+            U = unary.to(dtype)
+            with torch.no_grad():
+                cd = cdf(img.to(dtype))
+                q = U
+                for it in range(1, 11):
+                    msg = conv(act(local(q, cd)))
+                    logq = nn.LogSoftmax(dim=1)(torch.nn.functional.log_softmax(U, dim=1) - msg)
+                    q = torch.exp(logq)
+                    if it in (1, 2, 5, 10):
+                        extra[f"logq{tag}_it{it}"] = npy(logq)
+        save(f"meanfield_l{L}_h{H}_w{W}_k{k}", unary=npy(unary), img=npy(img), compat=npy(compat),
+             k=np.int64(k), pw=np.float32(pw), cw=np.float32(cw), **extra)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    args = ap.parse_args()
+    torch.set_num_threads(4)
+    LC, AM = import_reference(args.reference)
+    gen_color_distance(AM)
+    gen_local(LC)
+    gen_tail(AM)
+    gen_dpn(AM)
+    gen_meanfield(LC, AM)
+
+
+if __name__ == "__main__":
+    main()
