@@ -1,0 +1,148 @@
+/*
+ * mfl.h - C ABI of the MI355X (gfx950) local-window message-passing library.
+ *
+ * "mfl" = mean-field, local window.  The library replaces, for one hot path,
+ * what the reference computes with stock PyTorch ops:
+ *
+ *   Conv2dLocal.forward                     LocalConvolution.py:59-90
+ *   DPNModel._color_distance                AdvancedModel.py:520-551
+ *   autograd backward of Conv2dLocal        driven by AdvancedModel.py:299
+ *   BlockMinPooling + unary/smoothness      AdvancedModel.py:25-35, 242-244
+ *   combine + LogSoftmax
+ *   LinearActivation (per-pixel affine)     AdvancedModel.py:38-56
+ *
+ * The reference has no FFI of its own (it is pure Python); each entry point
+ * below names the Python symbol whose arithmetic it takes over, and
+ * INTEGRATION.md shows the ctypes binding a maintainer adds on the reference
+ * side.
+ *
+ * Conventions
+ *   - plain C, no torch types; every pointer is a BORROWED device pointer that
+ *     must stay valid until the work queued on `stream` has finished;
+ *   - tensors are fp32, contiguous NCHW: x[B][C][H][W]; pixels are flattened
+ *     row-major (l = y*W + x); the window is k x k with K = k*k taps flattened
+ *     ky*k + kx; zero padding is k/2 before and (k-1)/2 after on both axes;
+ *   - the library allocates nothing and never synchronises the device; scratch
+ *     memory is a caller-provided workspace whose size mfl_workspace_bytes()
+ *     reports; kernels are queued on `stream` (a hipStream_t passed as void*;
+ *     NULL = the default stream) of the device that is current at the call;
+ *   - potential parameters (position_weight, color_weight) are passed as device
+ *     pointers to one float each, so no host read-back is needed;
+ *   - every function returns 0 on success, a negative MFL_ERR_* code for a
+ *     rejected argument, or a positive hipError_t from the runtime.  Nothing
+ *     throws or aborts across this boundary.
+ */
+#ifndef MFL_H
+#define MFL_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFL_VERSION 100 /* 0.1.0 */
+
+#define MFL_OK 0
+#define MFL_ERR_INVALID_ARGUMENT (-1) /* null pointer, non-positive size, unsupported combination */
+#define MFL_ERR_WORKSPACE (-2)        /* workspace missing or smaller than mfl_workspace_bytes() */
+#define MFL_ERR_TOO_LARGE (-3)        /* a 32-bit index inside the kernels would overflow */
+
+/* operations for mfl_workspace_bytes() */
+#define MFL_OP_LOCAL_FORWARD 1
+#define MFL_OP_LOCAL_BACKWARD 2
+#define MFL_OP_MEANFIELD_FORWARD 3
+
+typedef void *mfl_stream_t;
+
+/* Library version (MFL_VERSION of the build). */
+int mfl_version(void);
+
+/* Static description of a return code (never NULL). */
+const char *mfl_error_string(int code);
+
+/*
+ * Bytes of device workspace the given operation needs for this problem size
+ * (0 if the operation needs none or the arguments are invalid).  `iters` is
+ * only read for MFL_OP_MEANFIELD_FORWARD.
+ */
+size_t mfl_workspace_bytes(int op, int B, int C, int H, int W, int k, int iters);
+
+/*
+ * Colour-distance tensor, materialised (the fused paths never need it; it exists
+ * for callers that want the tensor itself and for tests).
+ *   cd[b][l][t] = sum_ch (img[b][ch][y][x] - pad(img)[b][ch][y+ky][x+kx])^2
+ * Replaces DPNModel._color_distance / wrapped_color_distance,
+ * AdvancedModel.py:520-551.   img: [B][3][H][W]   cd: [B][H*W][k*k]
+ */
+int mfl_color_distance(const float *img, float *cd, int B, int H, int W, int k, mfl_stream_t stream);
+
+/*
+ * y = x * sum_t (pd[t]*pos_w + cdist[l][t]*col_w) * S[c][l][t], where S is the
+ * reference's permuted/reshaped im2col of zero-padded x and pd the squared tap
+ * offsets.  Replaces Conv2dLocal.forward, LocalConvolution.py:59-90, fused with
+ * the colour distance when `img` is given.
+ * Exactly one of `img` ([B][3][H][W]; the distance is recomputed on chip) and
+ * `cd` ([B][H*W][k*k]; read from memory) must be non-NULL.
+ *   x, y: [B][C][H][W]   pos_w, col_w: device pointers to 1 float
+ */
+int mfl_local_forward(const float *x, const float *img, const float *cd, const float *pos_w, const float *col_w,
+                      float *y, int B, int C, int H, int W, int k, void *workspace, size_t workspace_bytes,
+                      mfl_stream_t stream);
+
+/*
+ * Gradients of mfl_local_forward for an incoming dy (what autograd derives from
+ * LocalConvolution.py:74-90 when AdvancedModel.py:299 calls loss.backward()).
+ *   dx:      [B][C][H][W]
+ *   dparams: 2 floats, overwritten with {d position_weight, d color_weight}
+ *   dcd:     optional [B][H*W][k*k] gradient w.r.t. the colour-distance tensor
+ *            (NULL to skip; only allowed with `cd`)
+ * The scatter half of dx uses float atomics: its summation order, and therefore
+ * its last bits, can differ between runs.
+ */
+int mfl_local_backward(const float *x, const float *img, const float *cd, const float *pos_w, const float *col_w,
+                       const float *dy, float *dx, float *dparams, float *dcd, int B, int C, int H, int W, int k,
+                       void *workspace, size_t workspace_bytes, mfl_stream_t stream);
+
+/*
+ * logq = LogSoftmax_c( log_softmax_c(unary) - min_m smooth[b][m*C + c] ).
+ * Replaces BlockMinPooling.forward (AdvancedModel.py:32-35; pass mixtures = 1
+ * for a plain smoothness tensor) and the combine + final LogSoftmax,
+ * AdvancedModel.py:242-244.
+ *   unary, logq: [B][C][H][W]   smooth: [B][mixtures*C][H][W]
+ *   q: optional exp(logq), same shape (NULL to skip)
+ */
+int mfl_combine_forward(const float *unary, const float *smooth, int mixtures, float *logq, float *q, int B, int C,
+                        int H, int W, mfl_stream_t stream);
+
+/*
+ * `iters` fused mean-field updates.  Q_0 = unary (the reference feeds the raw
+ * unary to its local layer, AdvancedModel.py:222); each iteration computes
+ *   M    = Conv2dLocal(Q_t, colour distance of img)        LocalConvolution.py:59-90
+ *   M    = affine_w * M + affine_b        (optional)        AdvancedModel.py:52-56, 223
+ *   P    = compat . M                     (optional, CxC)   AdvancedModel.py:143-144 with a 1x1 kernel
+ *   logQ = LogSoftmax(log_softmax(unary) - P)               AdvancedModel.py:242-244
+ *   Q_{t+1} = exp(logQ)
+ * and the last logQ is written to `logq`.  iters = 1 without affine/compat is the
+ * reference's phase-4 data flow with the label-context block replaced by identity.
+ *   unary, logq: [B][C][H][W]   img: [B][3][H][W]
+ *   affine_w, affine_b: [C][H][W] or NULL (both or neither)
+ *   compat: [C][C] row-major (P[c] = sum_c' compat[c][c'] * M[c']) or NULL
+ */
+int mfl_meanfield_forward(const float *unary, const float *img, const float *pos_w, const float *col_w,
+                          const float *affine_w, const float *affine_b, const float *compat, float *logq, int B,
+                          int C, int H, int W, int k, int iters, void *workspace, size_t workspace_bytes,
+                          mfl_stream_t stream);
+
+/*
+ * labels[b][y][x] = argmax_c logq[b][c][y][x] (first maximum wins, as
+ * torch.argmax does for the reference's prediction_to_image,
+ * AdvancedModel.py:420-421).   labels: [B][H][W] uint8, C <= 256.
+ */
+int mfl_argmax_labels(const float *logq, unsigned char *labels, int B, int C, int H, int W, mfl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* MFL_H */

@@ -1,0 +1,523 @@
+// HIP kernels (gfx950) and the C ABI of the local-window message-passing library.
+// Declarations and the reference symbols each entry point replaces: include/mfl.h.
+//
+// Data layout in device memory
+//   x / unary / y / logq      fp32 NCHW as the caller holds them
+//   xp  (workspace)           zero-padded planes [B][C][Hp][Wp] (+ slack), Hp = H+k-1, Wp = W+k-1:
+//                             the gather never needs a bounds check, and the mean-field loop writes
+//                             Q_{t+1} straight into the interior of the next padded buffer
+//   ip4 (workspace)           zero-padded RGB image, one 16-byte {r,g,b,0} per pixel [B][Hp][Wp]:
+//                             one 16-byte load per (pixel, tap) for the colour distance
+//   tab (workspace)           CK int32 offsets, staged into LDS by every block
+//
+// Thread mapping, index map and the incremental decode: mfl_core.h; gather kernels: mfl_gather.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mfl.h"
+#include "mfl_gather.h"
+
+using namespace mfl;
+
+namespace {
+
+constexpr int kMaxLdsBytes = 60 * 1024;  // dynamic LDS one block may ask for without raising the launch limit
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+#define MFL_CHECK_HIP(expr)                          \
+    do {                                             \
+        hipError_t e_ = (expr);                      \
+        if (e_ != hipSuccess) return (int)e_;        \
+    } while (0)
+
+// ------------------------------------------------------------------ small kernels
+
+// dst[bc][yy][xx] = src[bc][yy-p0][xx-p0] inside the image, 0 on the border.
+__global__ void pad_planes_kernel(const float *__restrict__ src, float *__restrict__ dst, int planes, int H, int W,
+                                  int Hp, int Wp, int p0)
+{
+    const size_t n = (size_t)planes * Hp * Wp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % Wp);
+        const size_t rest = i / Wp;
+        const int yy = (int)(rest % Hp);
+        const size_t pc = rest / Hp;
+        const int y = yy - p0, x = xx - p0;
+        dst[i] = (y >= 0 && y < H && x >= 0 && x < W) ? src[(pc * H + y) * W + x] : 0.0f;
+    }
+}
+
+// dst[b][yy][xx] = {r, g, b, 0} of the padded image.
+__global__ void pad_image4_kernel(const float *__restrict__ img, F4 *__restrict__ dst, int B, int H, int W, int Hp,
+                                  int Wp, int p0)
+{
+    const size_t n = (size_t)B * Hp * Wp;
+    const size_t L = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % Wp);
+        const size_t rest = i / Wp;
+        const int yy = (int)(rest % Hp);
+        const size_t b = rest / Hp;
+        const int y = yy - p0, x = xx - p0;
+        F4 v = {0.f, 0.f, 0.f, 0.f};
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            const float *p = img + b * 3 * L + (size_t)y * W + x;
+            v.x = p[0]; v.y = p[L]; v.z = p[2 * L];
+        }
+        dst[i] = v;
+    }
+}
+
+__global__ void build_table_kernel(int *__restrict__ tab, Geom g)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < g.CK) tab[r] = table_entry(g, r);
+}
+
+// cd[b][l][t]: one thread per output element, consecutive lanes write consecutive taps.
+__global__ void color_distance_kernel(const float *__restrict__ img, float *__restrict__ cd, int B, int H, int W, int k)
+{
+    const int K = k * k, p0 = k / 2;
+    const size_t L = (size_t)H * W, n = (size_t)B * L * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % K);
+        const size_t bl = i / K;
+        const size_t l = bl % L, b = bl / L;
+        const int y = (int)(l / W), x = (int)(l % W);
+        const int ny = y + t / k - p0, nx = x + t % k - p0;
+        const bool in = ny >= 0 && ny < H && nx >= 0 && nx < W;
+        const float *p = img + b * 3 * L;
+        float s = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float d = p[ch * L + l] - (in ? p[ch * L + (size_t)ny * W + nx] : 0.f);
+            s += d * d;
+        }
+        cd[i] = s;
+    }
+}
+
+// logq = LogSoftmax(log_softmax(unary) - min_m smooth[m*C + c]); one thread per pixel, runtime C.
+// q (optional) = exp(logq), written either unpadded ([B][C][H][W], q_pad_k = 0) or into the
+// interior of zero-padded planes for a k x k window (q_pad_k = k).
+__global__ void combine_kernel(const float *__restrict__ unary, const float *__restrict__ smooth, int mixtures,
+                               float *__restrict__ logq, float *__restrict__ q, int q_pad_k, int B, int C, int H,
+                               int W)
+{
+    const size_t L = (size_t)H * W;
+    const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= (size_t)B * L) return;
+    const size_t b = pix / L, l = pix % L;
+    const float *u = unary + b * C * L + l;
+    const float *s = smooth + b * mixtures * C * L + l;
+
+    float mu = -INFINITY;
+    for (int c = 0; c < C; ++c) mu = fmaxf(mu, u[c * L]);
+    float su = 0.f;
+    for (int c = 0; c < C; ++c) su += expf(u[c * L] - mu);
+    const float lse_u = mu + logf(su);
+
+    auto v_at = [&](int c) {
+        float mn = s[c * L];
+        for (int m = 1; m < mixtures; ++m) mn = fminf(mn, s[((size_t)m * C + c) * L]);
+        return (u[c * L] - lse_u) - mn;
+    };
+    float mv = -INFINITY;
+    for (int c = 0; c < C; ++c) mv = fmaxf(mv, v_at(c));
+    float sv = 0.f;
+    for (int c = 0; c < C; ++c) sv += expf(v_at(c) - mv);
+    const float lse_v = mv + logf(sv);
+
+    size_t qoff = 0, qplane = L;
+    if (q) {
+        if (q_pad_k > 0) {
+            const int Wp = W + q_pad_k - 1, Hp = H + q_pad_k - 1, p0 = q_pad_k / 2;
+            qplane = (size_t)Hp * Wp;
+            qoff = b * C * qplane + (size_t)((int)(l / W) + p0) * Wp + (int)(l % W) + p0;
+        } else {
+            qoff = b * C * L + l;
+        }
+    }
+    for (int c = 0; c < C; ++c) {
+        const float lq = v_at(c) - lse_v;
+        if (logq) logq[b * C * L + c * L + l] = lq;
+        if (q) q[qoff + c * qplane] = expf(lq);
+    }
+}
+
+// msg <- compat . (aw * msg + ab), per pixel, runtime C (the large-label path; the fused
+// kernel does this in registers for C <= 32).  One block handles 64 pixels: the 64 x C tile of
+// messages is staged in LDS, the C x C matrix is read through the cache.
+__global__ void label_transform_kernel(const float *msg, const float *__restrict__ aw,
+                                       const float *__restrict__ ab, const float *__restrict__ compat,
+                                       float *out, int B, int C, int H, int W)
+{
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // [C][64]
+    const size_t L = (size_t)H * W;
+    const int px = threadIdx.x & 63, grp = threadIdx.x >> 6;       // 4 groups of 64 lanes
+    const size_t pix = (size_t)blockIdx.x * 64 + px;
+    const bool ok = pix < (size_t)B * L;
+    const size_t b = ok ? pix / L : 0, l = ok ? pix % L : 0;
+    for (int c = grp; c < C; c += 4) {
+        float v = ok ? msg[(b * C + c) * L + l] : 0.f;
+        if (aw) v = fmaf(aw[(size_t)c * L + l], v, ab[(size_t)c * L + l]);
+        tile[c * 64 + px] = v;
+    }
+    __syncthreads();
+    for (int c = grp; c < C; c += 4) {
+        float acc;
+        if (compat) {
+            acc = 0.f;
+            const float *row = compat + (size_t)c * C;
+            for (int c2 = 0; c2 < C; ++c2) acc = fmaf(row[c2], tile[c2 * 64 + px], acc);
+        } else {
+            acc = tile[c * 64 + px];
+        }
+        if (ok) out[(b * C + c) * L + l] = acc;
+    }
+}
+
+__global__ void argmax_kernel(const float *__restrict__ logq, unsigned char *__restrict__ labels, int B, int C, int H,
+                              int W)
+{
+    const size_t L = (size_t)H * W;
+    const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= (size_t)B * L) return;
+    const size_t b = pix / L, l = pix % L;
+    const float *p = logq + b * C * L + l;
+    float best = p[0];
+    int arg = 0;
+    for (int c = 1; c < C; ++c) {
+        const float v = p[c * L];
+        if (v > best) { best = v; arg = c; }
+    }
+    labels[pix] = (unsigned char)arg;
+}
+
+// dx = dxd + interior(dxp)
+__global__ void backward_finish_kernel(const float *__restrict__ dxd, const float *__restrict__ dxp,
+                                       float *__restrict__ dx, int planes, int H, int W, int Hp, int Wp, int p0)
+{
+    const size_t n = (size_t)planes * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const size_t rest = i / W;
+        const int y = (int)(rest % H);
+        const size_t pc = rest / H;
+        dx[i] = dxd[i] + dxp[(pc * Hp + y + p0) * Wp + x + p0];
+    }
+}
+
+// dparams[0..1] = sum over blocks of partials, one block, fixed order (deterministic), in double.
+__global__ void reduce_partials_kernel(const float *__restrict__ partials, int nblocks, float *__restrict__ dparams)
+{
+    __shared__ double sh[2][kThreads];
+    double a = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += kThreads) { a += partials[2 * i]; c += partials[2 * i + 1]; }
+    sh[0][threadIdx.x] = a;
+    sh[1][threadIdx.x] = c;
+    __syncthreads();
+    for (int s = kThreads / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { dparams[0] = (float)sh[0][0]; dparams[1] = (float)sh[1][0]; }
+}
+
+// ------------------------------------------------------------------ host side
+
+int grid_for(size_t n) { return (int)((n + kThreads - 1) / kThreads < 65535 * 16 ? (n + kThreads - 1) / kThreads : 65535 * 16); }
+
+// Channel-chunk widths the gather kernels are built for (mfl_gather.hip, -DMFL_CC=...).
+int pick_cc(int C)
+{
+    const int widths[] = {8, 19, 21, 32};
+    for (int w : widths)
+        if (C <= w) return w;
+    return 32;
+}
+
+int pick_m(const Geom &g1, int cc, int max_m)
+{
+    int m = choose_m(g1.L, g1.CK, max_m);
+    while (m > 1 && cc * m > 96) m >>= 1;   // accumulator tile within the register budget (kMaxM in mfl_gather.hip)
+    return m;
+}
+
+struct Workspace {
+    // carve-up of the caller's buffer; all offsets 256-byte aligned
+    size_t xp, xp2, ip4, tab, dxd, dxp, partials, msg, total;
+};
+
+size_t padded_floats(const Geom &g) { return (size_t)g.B * g.C * g.plane + padded_slack(g); }
+
+int backward_blocks(const Geom &g, int cc)
+{
+    return ((g.units + kThreads - 1) / kThreads) * ((g.C + cc - 1) / cc) * g.B;
+}
+
+Workspace carve(int op, const Geom &g, int cc)
+{
+    Workspace w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    w.xp = take(padded_floats(g) * 4);
+    w.ip4 = take(((size_t)g.B * g.plane + 64) * sizeof(F4));
+    w.tab = take((size_t)g.CK * 4);
+    if (op == MFL_OP_LOCAL_BACKWARD) {
+        w.dxd = take((size_t)g.B * g.C * g.L * 4);
+        w.dxp = take(padded_floats(g) * 4);
+        w.partials = take((size_t)backward_blocks(g, cc) * 2 * 4);
+    }
+    if (op == MFL_OP_MEANFIELD_FORWARD) {
+        w.xp2 = take(padded_floats(g) * 4);
+        if (g.C > 32) w.msg = take((size_t)g.B * g.C * g.L * 4);
+    }
+    w.total = off;
+    return w;
+}
+
+int check_common(const void *a, const void *b, int B, int C, int H, int W, int k)
+{
+    if (!a || !b) return MFL_ERR_INVALID_ARGUMENT;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0) return MFL_ERR_INVALID_ARGUMENT;
+    return MFL_OK;
+}
+
+int launch_prepare(const Geom &g, const float *x, const float *img, float *xp, F4 *ip4, int *tab, hipStream_t st)
+{
+    if (x) {
+        const size_t n = (size_t)g.B * g.C * g.plane;
+        hipLaunchKernelGGL(pad_planes_kernel, dim3(grid_for(n)), dim3(kThreads), 0, st, x, xp, g.B * g.C, g.H, g.W,
+                           g.Hp, g.Wp, g.p0);
+        MFL_CHECK_HIP(hipMemsetAsync(xp + n, 0, padded_slack(g) * 4, st));
+    }
+    if (img) {
+        const size_t n = (size_t)g.B * g.plane;
+        hipLaunchKernelGGL(pad_image4_kernel, dim3(grid_for(n)), dim3(kThreads), 0, st, img, ip4, g.B, g.H, g.W, g.Hp,
+                           g.Wp, g.p0);
+    }
+    hipLaunchKernelGGL(build_table_kernel, dim3((g.CK + kThreads - 1) / kThreads), dim3(kThreads), 0, st, tab, g);
+    return (int)hipGetLastError();
+}
+
+// ---- dispatch over the channel-chunk widths -----------------------------------
+#define MFL_BY_CC(cc, fn, ...)                    \
+    switch (cc) {                                 \
+    case 8: return fn##_cc8(__VA_ARGS__);         \
+    case 19: return fn##_cc19(__VA_ARGS__);       \
+    case 21: return fn##_cc21(__VA_ARGS__);       \
+    default: return fn##_cc32(__VA_ARGS__);       \
+    }
+
+int dispatch_local_forward(int cc, const GatherArgs &a, float *y, hipStream_t st)
+{
+    MFL_BY_CC(cc, launch_local_forward, a, y, st)
+}
+int dispatch_local_backward(int cc, const GatherArgs &a, const BackwardArgs &b, hipStream_t st)
+{
+    MFL_BY_CC(cc, launch_local_backward, a, b, st)
+}
+int dispatch_meanfield_step(int cc, const GatherArgs &a, const StepArgs &s, hipStream_t st)
+{
+    MFL_BY_CC(cc, launch_meanfield_step, a, s, st)
+}
+
+// Problem set-up shared by the gather entry points: geometry with the M the dispatcher will use.
+int setup(Geom &g, int &cc, bool &tab_lds, int B, int C, int H, int W, int k, bool from_cd, int max_m,
+          size_t extra_lds)
+{
+    Geom g1;
+    int rc = make_geom(g1, B, C, H, W, k, 1);
+    if (rc) return rc == -3 ? MFL_ERR_TOO_LARGE : MFL_ERR_INVALID_ARGUMENT;
+    cc = pick_cc(C);
+    tab_lds = (size_t)g1.CK * 4 + 16 + extra_lds <= (size_t)kMaxLdsBytes;
+    int m = (from_cd || !tab_lds) ? 1 : pick_m(g1, cc, max_m);
+    rc = make_geom(g, B, C, H, W, k, m);
+    if (rc) return rc == -3 ? MFL_ERR_TOO_LARGE : MFL_ERR_INVALID_ARGUMENT;
+    return MFL_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ C ABI
+
+extern "C" {
+
+int mfl_version(void) { return MFL_VERSION; }
+
+const char *mfl_error_string(int code)
+{
+    switch (code) {
+    case MFL_OK: return "success";
+    case MFL_ERR_INVALID_ARGUMENT: return "mfl: invalid argument";
+    case MFL_ERR_WORKSPACE: return "mfl: workspace missing or too small";
+    case MFL_ERR_TOO_LARGE: return "mfl: problem too large for 32-bit kernel indexing";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "mfl: unknown error";
+    }
+}
+
+size_t mfl_workspace_bytes(int op, int B, int C, int H, int W, int k, int iters)
+{
+    (void)iters;
+    if (op != MFL_OP_LOCAL_FORWARD && op != MFL_OP_LOCAL_BACKWARD && op != MFL_OP_MEANFIELD_FORWARD) return 0;
+    Geom g;
+    if (make_geom(g, B, C, H, W, k, 1)) return 0;
+    return carve(op, g, pick_cc(C)).total;
+}
+
+int mfl_color_distance(const float *img, float *cd, int B, int H, int W, int k, mfl_stream_t stream)
+{
+    int rc = check_common(img, cd, B, 1, H, W, k);
+    if (rc) return rc;
+    const size_t n = (size_t)B * H * W * k * k;
+    hipLaunchKernelGGL(color_distance_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, img, cd, B, H,
+                       W, k);
+    return (int)hipGetLastError();
+}
+
+int mfl_local_forward(const float *x, const float *img, const float *cd, const float *pos_w, const float *col_w,
+                      float *y, int B, int C, int H, int W, int k, void *workspace, size_t workspace_bytes,
+                      mfl_stream_t stream)
+{
+    int rc = check_common(x, y, B, C, H, W, k);
+    if (rc) return rc;
+    if (!pos_w || !col_w || (img == nullptr) == (cd == nullptr)) return MFL_ERR_INVALID_ARGUMENT;
+    Geom g;
+    int cc;
+    bool tab_lds;
+    rc = setup(g, cc, tab_lds, B, C, H, W, k, cd != nullptr, 4, 0);
+    if (rc) return rc;
+    const Workspace ws = carve(MFL_OP_LOCAL_FORWARD, g, cc);
+    if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
+    char *base = (char *)workspace;
+    float *xp = (float *)(base + ws.xp);
+    F4 *ip4 = (F4 *)(base + ws.ip4);
+    int *tab = (int *)(base + ws.tab);
+    hipStream_t st = (hipStream_t)stream;
+    rc = launch_prepare(g, x, img, xp, ip4, tab, st);
+    if (rc) return rc;
+    const GatherArgs ga{g, cd != nullptr, tab_lds, xp, ip4, cd, tab, pos_w, col_w};
+    return dispatch_local_forward(cc, ga, y, st);
+}
+
+int mfl_local_backward(const float *x, const float *img, const float *cd, const float *pos_w, const float *col_w,
+                       const float *dy, float *dx, float *dparams, float *dcd, int B, int C, int H, int W, int k,
+                       void *workspace, size_t workspace_bytes, mfl_stream_t stream)
+{
+    int rc = check_common(x, dy, B, C, H, W, k);
+    if (rc) return rc;
+    if (!dx || !dparams || !pos_w || !col_w || (img == nullptr) == (cd == nullptr)) return MFL_ERR_INVALID_ARGUMENT;
+    if (dcd && !cd) return MFL_ERR_INVALID_ARGUMENT;
+    Geom g;
+    int cc;
+    bool tab_lds;
+    rc = setup(g, cc, tab_lds, B, C, H, W, k, cd != nullptr, 2, 0);
+    if (rc) return rc;
+    const Workspace ws = carve(MFL_OP_LOCAL_BACKWARD, g, cc);
+    if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
+    char *base = (char *)workspace;
+    float *xp = (float *)(base + ws.xp);
+    F4 *ip4 = (F4 *)(base + ws.ip4);
+    int *tab = (int *)(base + ws.tab);
+    float *dxd = (float *)(base + ws.dxd);
+    float *dxp = (float *)(base + ws.dxp);
+    float *partials = (float *)(base + ws.partials);
+    hipStream_t st = (hipStream_t)stream;
+    rc = launch_prepare(g, x, img, xp, ip4, tab, st);
+    if (rc) return rc;
+    MFL_CHECK_HIP(hipMemsetAsync(dxp, 0, padded_floats(g) * 4, st));
+    const int nchunks = (g.C + cc - 1) / cc;
+    if (dcd && nchunks > 1) MFL_CHECK_HIP(hipMemsetAsync(dcd, 0, (size_t)B * g.L * g.K * 4, st));
+    const GatherArgs ga{g, cd != nullptr, tab_lds, xp, ip4, cd, tab, pos_w, col_w};
+    const BackwardArgs ba{dy, dxd, dxp, partials, dcd};
+    rc = dispatch_local_backward(cc, ga, ba, st);
+    if (rc) return rc;
+    const size_t n = (size_t)B * C * g.L;
+    hipLaunchKernelGGL(backward_finish_kernel, dim3(grid_for(n)), dim3(kThreads), 0, st, dxd, dxp, dx, B * C, H, W,
+                       g.Hp, g.Wp, g.p0);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kThreads), 0, st, partials, backward_blocks(g, cc),
+                       dparams);
+    return (int)hipGetLastError();
+}
+
+int mfl_combine_forward(const float *unary, const float *smooth, int mixtures, float *logq, float *q, int B, int C,
+                        int H, int W, mfl_stream_t stream)
+{
+    int rc = check_common(unary, smooth, B, C, H, W, 1);
+    if (rc) return rc;
+    if (!logq || mixtures <= 0) return MFL_ERR_INVALID_ARGUMENT;
+    const size_t n = (size_t)B * H * W;
+    hipLaunchKernelGGL(combine_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       (hipStream_t)stream, unary, smooth, mixtures, logq, q, 0, B, C, H, W);
+    return (int)hipGetLastError();
+}
+
+int mfl_meanfield_forward(const float *unary, const float *img, const float *pos_w, const float *col_w,
+                          const float *affine_w, const float *affine_b, const float *compat, float *logq, int B,
+                          int C, int H, int W, int k, int iters, void *workspace, size_t workspace_bytes,
+                          mfl_stream_t stream)
+{
+    int rc = check_common(unary, img, B, C, H, W, k);
+    if (rc) return rc;
+    if (!logq || !pos_w || !col_w || iters <= 0 || (affine_w == nullptr) != (affine_b == nullptr))
+        return MFL_ERR_INVALID_ARGUMENT;
+    const bool fused = C <= 32;
+    Geom g;
+    int cc;
+    bool tab_lds;
+    rc = setup(g, cc, tab_lds, B, C, H, W, k, false, 4, fused ? (size_t)C * C * 4 : 0);
+    if (rc) return rc;
+    const Workspace ws = carve(MFL_OP_MEANFIELD_FORWARD, g, cc);
+    if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
+    char *base = (char *)workspace;
+    float *qa = (float *)(base + ws.xp), *qb = (float *)(base + ws.xp2);
+    F4 *ip4 = (F4 *)(base + ws.ip4);
+    int *tab = (int *)(base + ws.tab);
+    float *msg = (float *)(base + ws.msg);
+    hipStream_t st = (hipStream_t)stream;
+    rc = launch_prepare(g, unary, img, qa, ip4, tab, st);          // Q_0 = unary, padded
+    if (rc) return rc;
+    MFL_CHECK_HIP(hipMemsetAsync(qb, 0, padded_floats(g) * 4, st)); // borders of the other buffer
+    const size_t npix = (size_t)B * g.L;
+    for (int it = 0; it < iters; ++it) {
+        float *lq = (it == iters - 1) ? logq : nullptr;
+        if (fused) {
+            const GatherArgs ga{g, false, tab_lds, qa, ip4, nullptr, tab, pos_w, col_w};
+            const StepArgs sa{unary, affine_w, affine_b, compat, lq, qb};
+            rc = dispatch_meanfield_step(cc, ga, sa, st);
+            if (rc) return rc;
+        } else {
+            const GatherArgs ga{g, false, tab_lds, qa, ip4, nullptr, tab, pos_w, col_w};
+            rc = dispatch_local_forward(cc, ga, msg, st);
+            if (rc) return rc;
+            if (affine_w || compat) {
+                hipLaunchKernelGGL(label_transform_kernel, dim3((unsigned)((npix + 63) / 64)), dim3(kThreads),
+                                   (size_t)C * 64 * 4, st, msg, affine_w, affine_b, compat, msg, B, C, H, W);
+            }
+            hipLaunchKernelGGL(combine_kernel, dim3((unsigned)((npix + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                               st, unary, msg, 1, lq, qb, k, B, C, H, W);
+            rc = (int)hipGetLastError();
+            if (rc) return rc;
+        }
+        float *t = qa; qa = qb; qb = t;
+    }
+    return MFL_OK;
+}
+
+int mfl_argmax_labels(const float *logq, unsigned char *labels, int B, int C, int H, int W, mfl_stream_t stream)
+{
+    int rc = check_common(logq, labels, B, C, H, W, 1);
+    if (rc) return rc;
+    if (C > 256) return MFL_ERR_INVALID_ARGUMENT;
+    const size_t n = (size_t)B * H * W;
+    hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       (hipStream_t)stream, logq, labels, B, C, H, W);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,266 @@
+// Geometry and the per-thread gather core of the local-window message-passing
+// kernels.  Shared by the HIP kernels (device) and by the host emulation used in
+// the CPU test-suite, so it is written in plain C++ with a few macros.
+//
+// Arithmetic restated (not code) from Conv2dLocal.forward, LocalConvolution.py:59-90.
+//
+// ---- the index map ---------------------------------------------------------
+// With K = k*k taps, L = H*W pixels and CK = C*K, the reference's
+// Unfold -> permute(0,2,1) -> reshape(B,C,K,-1) makes output (c, l), tap t read
+//     V[g],  g = (c*K + t)*L + l,
+// where V is the im2col array in [pixel l'][channel c'][tap t'] order:
+//     V[l'*CK + c'*K + t'] = pad(x)[c'][l'/W + t'/k][l'%W + t'%k].
+// Row j = c*K + t of the [CK][L] view of V therefore holds, for consecutive
+// output pixels l, consecutive (c', t') entries of one or two source pixels l'.
+//
+// ---- thread mapping ---------------------------------------------------------
+// A thread owns M output pixels l_n = l_0 + n*CK (n < M) and all channels of a
+// channel chunk.  For any row j the M values it needs are V[g_0 + n*CK]: the
+// SAME (c', t') of M horizontally consecutive source pixels l', l'+1, ...,
+// i.e. M consecutive floats of one padded row (unless the run crosses the end
+// of an image row).  One address decode therefore serves M gathers, and the
+// gathers are one M-wide load.  "Units" number the (tile, t_0) pairs:
+//     unit u -> tile i = u / CK, t_0 = u % CK, l_0 = i*M*CK + t_0.
+//
+// ---- incremental decode ------------------------------------------------------
+// Per thread the decode state of row j is (r, y', x') with g_0 = l'*CK + r,
+// l' = y'*W + x'.  Moving to the next channel (j += K) or the next tap
+// (j += 1) adds a constant to g_0, so the state advances with adds and
+// carries only; host-computed constants:
+//     L   = q *CK + rho,   q  = dqy*W + dqx       (tap step)
+//     K*L = qK*CK + rhoK,  qK = dKy*W + dKx       (channel step)
+// The address of the run is  y'*Wp + x' + tab[r]  in the padded plane set of
+// the image, tab[r] = c'*plane + (t'/k)*Wp + t'%k  (a CK-entry table).
+#ifndef MFL_CORE_H
+#define MFL_CORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MFL_HD __host__ __device__ __forceinline__
+#define MFL_D __device__ __forceinline__
+#else
+#include <math.h>
+#define MFL_HD inline
+#define MFL_D inline
+#endif
+
+namespace mfl {
+
+struct alignas(16) F4 {
+    float x, y, z, w;
+};
+
+// 4-byte aligned vector views: gfx950 global loads only need dword alignment.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+struct Geom {
+    int B, C, H, W, k, K, p0;
+    int L, CK;
+    int Hp, Wp, plane;  // zero-padded plane: Hp = H+k-1 rows of Wp = W+k-1 floats
+    int M, ntile, units;
+    int q, rho, dqy, dqx;
+    int qK, rhoK, dKy, dKx;
+};
+
+// Floats of slack required after the last padded plane: tail threads and
+// out-of-range columns of the last tile read (never use) up to M pixels past
+// the last source pixel.
+MFL_HD size_t padded_slack(const Geom &g) { return (size_t)3 * g.Wp + 64; }
+
+// Pick M (1, 2 or 4 pixels per thread) for a problem: the largest M whose
+// tiles are at least 85 % full.
+inline int choose_m(long long L, long long CK, int max_m)
+{
+    for (int m = max_m; m > 1; m >>= 1) {
+        long long tile = (long long)m * CK;
+        long long nt = (L + tile - 1) / tile;
+        if ((double)L / (double)(nt * tile) >= 0.85) return m;
+    }
+    return 1;
+}
+
+// Returns 0 on success, -1 for invalid sizes, -3 when 32-bit indexing would overflow.
+inline int make_geom(Geom &g, int B, int C, int H, int W, int k, int M)
+{
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0 || M <= 0) return -1;
+    const long long K = (long long)k * k, L = (long long)H * W, CK = (long long)C * K;
+    const long long Hp = (long long)H + k - 1, Wp = (long long)W + k - 1, plane = Hp * Wp;
+    if (L >= (1LL << 30) || CK >= (1LL << 30) || C * plane + 3 * Wp + 64 >= (1LL << 29)) return -3;
+    g.B = B; g.C = C; g.H = H; g.W = W; g.k = k; g.K = (int)K; g.p0 = k / 2;
+    g.L = (int)L; g.CK = (int)CK; g.Hp = (int)Hp; g.Wp = (int)Wp; g.plane = (int)plane;
+    g.M = M;
+    const long long tile = (long long)M * CK;
+    g.ntile = (int)((L + tile - 1) / tile);
+    if ((long long)g.ntile * CK >= (1LL << 31)) return -3;
+    g.units = (int)((long long)g.ntile * CK);
+    g.q = (int)(L / CK); g.rho = (int)(L % CK);
+    g.dqy = g.q / W; g.dqx = g.q % W;
+    const long long KL = K * L;
+    g.qK = (int)(KL / CK); g.rhoK = (int)(KL % CK);
+    g.dKy = g.qK / W; g.dKx = g.qK % W;
+    // initial decode uses c0*rhoK + l0 in 32 bits
+    if ((long long)C * g.rhoK + L + CK >= (1LL << 31)) return -3;
+    return 0;
+}
+
+MFL_HD int table_entry(const Geom &g, int r)
+{
+    const int cp = r / g.K, tp = r - cp * g.K;
+    const int ky = tp / g.k, kx = tp - ky * g.k;
+    return cp * g.plane + ky * g.Wp + kx;
+}
+
+// Load the M floats of a run starting at p whose first source pixel has column
+// x in an image row of W pixels; a run that crosses the row end continues
+// `gap` = Wp - W floats later (first pixel of the next padded row).
+template <int M>
+MFL_D void load_run(float (&v)[M], const float *p, int x, int W, int gap)
+{
+    if constexpr (M == 1) {
+        v[0] = p[0];
+    } else {
+        const bool crosses = (x + M > W);
+#if defined(__HIP_DEVICE_COMPILE__)
+        const bool any_cross = __builtin_amdgcn_ballot_w64(crosses) != 0;   // wave-uniform branch
+#else
+        const bool any_cross = crosses;
+#endif
+        if (!any_cross) {
+            if constexpr (M == 2) {
+                const f2u t = *reinterpret_cast<const f2u *>(p);
+                v[0] = t.x; v[1] = t.y;
+            } else {
+#pragma unroll
+                for (int n = 0; n < M; n += 4) {
+                    const f4u t = *reinterpret_cast<const f4u *>(p + n);
+                    v[n] = t.x; v[n + 1] = t.y; v[n + 2] = t.z; v[n + 3] = t.w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < M; ++n) v[n] = p[n + ((x + n >= W) ? gap : 0)];
+        }
+    }
+}
+
+// Per-thread column set of unit u (see header comment).
+template <int M>
+struct Columns {
+    int l0;          // first column, clamped into [0, L)
+    int lcl[M];      // column n clamped into [0, L)
+    int ibase[M];    // y_n*Wp + x_n: top-left corner of column n's window in a padded plane
+    bool valid[M];   // column n exists and this thread is not a grid-tail duplicate
+};
+
+template <int M>
+MFL_D void make_columns(Columns<M> &col, const Geom &g, int unit, bool thread_active)
+{
+    const int i = unit / g.CK, t0 = unit - i * g.CK;
+    const int l0 = i * (M * g.CK) + t0;
+    col.l0 = l0 < g.L ? l0 : g.L - 1;
+#pragma unroll
+    for (int n = 0; n < M; ++n) {
+        const int ln = l0 + n * g.CK;
+        col.valid[n] = thread_active && ln < g.L;
+        const int lc = ln < g.L ? ln : g.L - 1;
+        const int y = lc / g.W;
+        col.lcl[n] = lc;
+        col.ibase[n] = y * g.Wp + (lc - y * g.W);
+    }
+}
+
+// acc[cc][n] += sum over the K taps of w[n][t] * S[c0+cc][l_n][t]   (cc < nch)
+//   xp_b  zero-padded planes of image b: [C][Hp][Wp] (+ slack)
+//   ip_b  zero-padded RGB image of image b as F4 per pixel: [Hp][Wp]   (FROM_CD = false)
+//   cd_b  colour-distance tensor of image b: [L][K]                     (FROM_CD = true)
+//   tab   CK-entry offset table (LDS or global)
+// A Sink with enabled = true (the backward kernels) additionally receives
+//   scatter(a, x, cc, w)   once per (tap, channel): the run address and the tap weights,
+//   tap(t, pd, cdv, u)     once per tap, u[n] = sum_cc dmul[cc][n] * S[c0+cc][l_n][t].
+struct NoSink {
+    static constexpr bool enabled = false;
+};
+
+template <int CC, int M, bool FROM_CD, class TabPtr, class Sink>
+MFL_D void window_sums(float (&acc)[CC][M], const Geom &g, const float *__restrict__ xp_b,
+                       const F4 *__restrict__ ip_b, const float *__restrict__ cd_b, TabPtr tab, float pw, float cw,
+                       int c0, int nch, const Columns<M> &col, const float (*dmul)[M], Sink &sink)
+{
+    const int tmp = c0 * g.rhoK + col.l0;
+    const int lp = c0 * g.qK + tmp / g.CK;
+    int rs = tmp % g.CK;
+    int ys = lp / g.W;
+    int xs = lp - ys * g.W;
+    const int gap = g.Wp - g.W;
+
+    F4 ctr[M];
+    if constexpr (!FROM_CD) {
+        const int ctr_off = g.p0 * g.Wp + g.p0;
+#pragma unroll
+        for (int n = 0; n < M; ++n) ctr[n] = ip_b[col.ibase[n] + ctr_off];
+    }
+
+    int t = 0;
+    for (int ky = 0; ky < g.k; ++ky) {
+        for (int kx = 0; kx < g.k; ++kx, ++t) {
+            const int dy = ky - g.p0, dx = kx - g.p0;
+            const float pd = (float)(dy * dy + dx * dx);
+            const float pdw = pd * pw;
+            float w[M], cdv[M];
+#pragma unroll
+            for (int n = 0; n < M; ++n) {
+                if constexpr (FROM_CD) {
+                    cdv[n] = cd_b[(size_t)col.lcl[n] * g.K + t];
+                } else {
+                    const F4 nb = ip_b[col.ibase[n] + ky * g.Wp + kx];
+                    const float d0 = ctr[n].x - nb.x, d1 = ctr[n].y - nb.y, d2 = ctr[n].z - nb.z;
+                    cdv[n] = d0 * d0 + d1 * d1 + d2 * d2;
+                }
+                w[n] = fmaf(cdv[n], cw, pdw);
+            }
+            float u[M];
+#pragma unroll
+            for (int n = 0; n < M; ++n) u[n] = 0.0f;
+
+            int r = rs, y = ys, x = xs;
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc) {
+                if (cc < nch) {
+                    const int a = y * g.Wp + x + tab[r];
+                    float v[M];
+                    load_run<M>(v, xp_b + a, x, g.W, gap);
+#pragma unroll
+                    for (int n = 0; n < M; ++n) acc[cc][n] = fmaf(w[n], v[n], acc[cc][n]);
+                    if constexpr (Sink::enabled) {
+#pragma unroll
+                        for (int n = 0; n < M; ++n) u[n] = fmaf(dmul[cc][n], v[n], u[n]);
+                        sink.scatter(a, x, cc, w);
+                    }
+                    r += g.rhoK;
+                    const int carry = r >= g.CK;
+                    r -= carry ? g.CK : 0;
+                    x += g.dKx + carry;
+                    const int wrap = x >= g.W;
+                    x -= wrap ? g.W : 0;
+                    y += g.dKy + wrap;
+                }
+            }
+            if constexpr (Sink::enabled) sink.tap(t, pd, cdv, u);
+
+            rs += g.rho;
+            const int carry = rs >= g.CK;
+            rs -= carry ? g.CK : 0;
+            xs += g.dqx + carry;
+            const int wrap = xs >= g.W;
+            xs -= wrap ? g.W : 0;
+            ys += g.dqy + wrap;
+        }
+    }
+}
+
+}  // namespace mfl
+
+#endif  // MFL_CORE_H

@@ -1,0 +1,48 @@
+// Internal interface between the C-ABI translation unit (mfl_api.hip) and the
+// gather-kernel translation units (mfl_gather.hip, compiled once per channel-chunk
+// width CC with -DMFL_CC=<width> so that the widths build in parallel).
+#ifndef MFL_GATHER_H
+#define MFL_GATHER_H
+
+#include <hip/hip_runtime.h>
+
+#include "mfl_core.h"
+
+namespace mfl {
+
+constexpr int kThreads = 256;
+
+struct GatherArgs {
+    Geom g;                 // g.M selects the pixels-per-thread variant
+    bool from_cd;           // weights from a colour-distance tensor instead of the padded image
+    bool tab_lds;           // offset table staged in LDS (else read from global memory)
+    const float *xp;        // padded planes [B][C][Hp][Wp]
+    const F4 *ip4;          // padded image  [B][Hp][Wp]      (from_cd == false)
+    const float *cd;        // [B][L][K]                       (from_cd == true)
+    const int *tab;         // CK offsets
+    const float *pos_w, *col_w;
+};
+
+struct BackwardArgs {
+    const float *dy;
+    float *dxd, *dxp, *partials, *dcd;
+};
+
+struct StepArgs {
+    const float *unary, *aw, *ab, *compat;
+    float *logq, *qp_out;
+};
+
+#define MFL_DECLARE_GATHER(CCV)                                                                            \
+    int launch_local_forward_cc##CCV(const GatherArgs &a, float *y, hipStream_t st);                       \
+    int launch_local_backward_cc##CCV(const GatherArgs &a, const BackwardArgs &b, hipStream_t st);         \
+    int launch_meanfield_step_cc##CCV(const GatherArgs &a, const StepArgs &s, hipStream_t st);
+
+MFL_DECLARE_GATHER(8)
+MFL_DECLARE_GATHER(19)
+MFL_DECLARE_GATHER(21)
+MFL_DECLARE_GATHER(32)
+
+}  // namespace mfl
+
+#endif  // MFL_GATHER_H

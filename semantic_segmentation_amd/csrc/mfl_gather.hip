@@ -1,0 +1,387 @@
+// Gather kernels of the local-window message-passing library (gfx950), one
+// translation unit per channel-chunk width: compile with -DMFL_CC=<8|19|21|32>.
+// Thread mapping, index map and incremental decode: mfl_core.h.  Data layout and
+// the C ABI: mfl_api.hip, include/mfl.h.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mfl.h"
+#include "mfl_gather.h"
+
+#ifndef MFL_CC
+#error "compile with -DMFL_CC=<channel chunk width>"
+#endif
+
+using namespace mfl;
+
+namespace {
+
+
+template <bool TAB_LDS>
+__device__ __forceinline__ const int *stage_table(const int *__restrict__ tab_g, int *lds, int CK)
+{
+    if constexpr (TAB_LDS) {
+        for (int r = threadIdx.x; r < CK; r += kThreads) lds[r] = tab_g[r];
+        __syncthreads();
+        return lds;
+    } else {
+        return tab_g;
+    }
+}
+
+// y[b][c][l] = x[b][c][l] * sum_t w[b][l][t] * S[b][c][l][t]
+// grid: (ceil(units / 256), channel chunks, B)
+template <int CC, int M, bool FROM_CD, bool TAB_LDS>
+__global__ void __launch_bounds__(kThreads)
+local_forward_kernel(Geom g, const float *__restrict__ xp, const F4 *__restrict__ ip4, const float *__restrict__ cd,
+                     const int *__restrict__ tab_g, const float *__restrict__ pos_w, const float *__restrict__ col_w,
+                     float *__restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) int lds_tab[];
+    const int *tab = stage_table<TAB_LDS>(tab_g, lds_tab, g.CK);
+
+    const int b = blockIdx.z, c0 = blockIdx.y * CC;
+    const int nch = min(CC, g.C - c0);
+    const int uraw = blockIdx.x * kThreads + threadIdx.x;
+    Columns<M> col;
+    make_columns<M>(col, g, min(uraw, g.units - 1), uraw < g.units);
+
+    const float *xp_b = xp + (size_t)b * g.C * g.plane;
+    const F4 *ip_b = FROM_CD ? nullptr : ip4 + (size_t)b * g.plane;
+    const float *cd_b = FROM_CD ? cd + (size_t)b * g.L * g.K : nullptr;
+
+    float acc[CC][M];
+#pragma unroll
+    for (int cc = 0; cc < CC; ++cc)
+#pragma unroll
+        for (int n = 0; n < M; ++n) acc[cc][n] = 0.f;
+
+    NoSink sink;
+    if constexpr (TAB_LDS)
+        window_sums<CC, M, FROM_CD>(acc, g, xp_b, ip_b, cd_b, lds_tab, *pos_w, *col_w, c0, nch, col, nullptr, sink);
+    else
+        window_sums<CC, M, FROM_CD>(acc, g, xp_b, ip_b, cd_b, tab, *pos_w, *col_w, c0, nch, col, nullptr, sink);
+
+    const int ctr_off = g.p0 * g.Wp + g.p0;
+    float *y_b = y + (size_t)b * g.C * g.L;
+#pragma unroll
+    for (int n = 0; n < M; ++n) {
+        if (col.valid[n]) {
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc)
+                if (cc < nch) {
+                    const int c = c0 + cc;
+                    y_b[(size_t)c * g.L + col.lcl[n]] = acc[cc][n] * xp_b[(size_t)c * g.plane + col.ibase[n] + ctr_off];
+                }
+        }
+    }
+}
+
+// One fused mean-field update (all C <= CC channels of a pixel live in one thread):
+//   msg = Q_t * window_sum(Q_t);  msg = aw*msg + ab;  P = compat . msg;
+//   logQ = LogSoftmax(log_softmax(U) - P);  Q_{t+1} = exp(logQ) -> interior of qp_out
+// grid: (ceil(units / 256), 1, B).  LDS: [offset table][compat matrix].
+template <int CC, int M, bool TAB_LDS>
+__global__ void __launch_bounds__(kThreads)
+meanfield_step_kernel(Geom g, const float *__restrict__ qp_in, const F4 *__restrict__ ip4,
+                      const int *__restrict__ tab_g, const float *__restrict__ pos_w, const float *__restrict__ col_w,
+                      const float *__restrict__ unary, const float *__restrict__ aw, const float *__restrict__ ab,
+                      const float *__restrict__ compat, float *__restrict__ logq, float *__restrict__ qp_out)
+{
+    extern __shared__ __attribute__((aligned(16))) int lds_tab[];
+    float *lds_compat = reinterpret_cast<float *>(lds_tab + (TAB_LDS ? ((g.CK + 3) & ~3) : 0));
+    if (compat)
+        for (int i = threadIdx.x; i < g.C * g.C; i += kThreads) lds_compat[i] = compat[i];
+    const int *tab = stage_table<TAB_LDS>(tab_g, lds_tab, g.CK);
+    if constexpr (!TAB_LDS) __syncthreads();
+
+    const int b = blockIdx.z, C = g.C;
+    const int uraw = blockIdx.x * kThreads + threadIdx.x;
+    Columns<M> col;
+    make_columns<M>(col, g, min(uraw, g.units - 1), uraw < g.units);
+
+    const float *qp_b = qp_in + (size_t)b * C * g.plane;
+    const F4 *ip_b = ip4 + (size_t)b * g.plane;
+
+    float acc[CC][M];
+#pragma unroll
+    for (int cc = 0; cc < CC; ++cc)
+#pragma unroll
+        for (int n = 0; n < M; ++n) acc[cc][n] = 0.f;
+
+    NoSink sink;
+    if constexpr (TAB_LDS)
+        window_sums<CC, M, false>(acc, g, qp_b, ip_b, nullptr, lds_tab, *pos_w, *col_w, 0, C, col, nullptr, sink);
+    else
+        window_sums<CC, M, false>(acc, g, qp_b, ip_b, nullptr, tab, *pos_w, *col_w, 0, C, col, nullptr, sink);
+
+    const int ctr_off = g.p0 * g.Wp + g.p0;
+    const float *u_b = unary + (size_t)b * C * g.L;
+    float *qo_b = qp_out + (size_t)b * C * g.plane;
+#pragma unroll
+    for (int n = 0; n < M; ++n) {
+        if (!col.valid[n]) continue;
+        const int l = col.lcl[n], ci = col.ibase[n] + ctr_off;
+        float m[CC], u[CC];
+        float mu = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < CC; ++c)
+            if (c < C) {
+                float v = acc[c][n] * qp_b[(size_t)c * g.plane + ci];
+                if (aw) v = fmaf(aw[(size_t)c * g.L + l], v, ab[(size_t)c * g.L + l]);
+                m[c] = v;
+                u[c] = u_b[(size_t)c * g.L + l];
+                mu = fmaxf(mu, u[c]);
+            }
+        float su = 0.f;
+#pragma unroll
+        for (int c = 0; c < CC; ++c)
+            if (c < C) su += expf(u[c] - mu);
+        const float lse_u = mu + logf(su);
+        float mv = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < CC; ++c)
+            if (c < C) {
+                float p;
+                if (compat) {
+                    p = 0.f;
+#pragma unroll
+                    for (int c2 = 0; c2 < CC; ++c2)
+                        if (c2 < C) p = fmaf(lds_compat[c * C + c2], m[c2], p);
+                } else {
+                    p = m[c];
+                }
+                u[c] = (u[c] - lse_u) - p;
+                mv = fmaxf(mv, u[c]);
+            }
+        float sv = 0.f;
+#pragma unroll
+        for (int c = 0; c < CC; ++c)
+            if (c < C) sv += expf(u[c] - mv);
+        const float lse_v = mv + logf(sv);
+#pragma unroll
+        for (int c = 0; c < CC; ++c)
+            if (c < C) {
+                const float lq = u[c] - lse_v;
+                if (logq) logq[((size_t)b * C + c) * g.L + l] = lq;
+                qo_b[(size_t)c * g.plane + ci] = expf(lq);
+            }
+    }
+}
+
+// Backward of local_forward_kernel.  Mirrors the forward loop: the same gather gives
+// S, from which  out (for dx = dy*out), u_t = sum_c D*S (for the two parameter
+// gradients and dcd) follow, and the scatter half of dx is added with float atomics
+// into zero-initialised padded planes dxp.  D = dy * x.
+//   dxd       [B][C][H][W]   <- dy * out        (plain stores, one owner per element)
+//   dxp       [B][C][Hp][Wp] += D * w           (atomics)
+//   partials  [blocks][2]    <- per-block sums of {d pos_w, d col_w}
+template <int M>
+struct BackwardSink {
+    static constexpr bool enabled = true;
+    float *dxp_b;
+    const float (*D)[M];
+    const bool *valid;
+    int W, gap;
+    float tpw, tcw;
+    float *dcd_b;      // optional [L][K]
+    const int *lcl;
+    int K;
+    float cw;
+    bool dcd_atomic;
+
+    __device__ __forceinline__ void scatter(int a, int x, int cc, const float (&w)[M])
+    {
+#pragma unroll
+        for (int n = 0; n < M; ++n)
+            if (valid[n]) atomicAdd(dxp_b + a + n + ((x + n >= W) ? gap : 0), w[n] * D[cc][n]);
+    }
+    __device__ __forceinline__ void tap(int t, float pd, const float (&cdv)[M], const float (&u)[M])
+    {
+#pragma unroll
+        for (int n = 0; n < M; ++n)
+            if (valid[n]) {
+                tpw = fmaf(pd, u[n], tpw);
+                tcw = fmaf(cdv[n], u[n], tcw);
+                if (dcd_b) {
+                    float *p = dcd_b + (size_t)lcl[n] * K + t;
+                    if (dcd_atomic) atomicAdd(p, cw * u[n]);
+                    else *p = cw * u[n];
+                }
+            }
+    }
+};
+
+template <int CC, int M, bool FROM_CD, bool TAB_LDS>
+__global__ void __launch_bounds__(kThreads)
+local_backward_kernel(Geom g, const float *__restrict__ xp, const F4 *__restrict__ ip4, const float *__restrict__ cd,
+                      const int *__restrict__ tab_g, const float *__restrict__ pos_w, const float *__restrict__ col_w,
+                      const float *__restrict__ dy, float *__restrict__ dxd, float *__restrict__ dxp,
+                      float *__restrict__ partials, float *__restrict__ dcd)
+{
+    extern __shared__ __attribute__((aligned(16))) int lds_tab[];
+    __shared__ float red[2][kThreads / 64];
+    const int *tab = stage_table<TAB_LDS>(tab_g, lds_tab, g.CK);
+
+    const int b = blockIdx.z, c0 = blockIdx.y * CC;
+    const int nch = min(CC, g.C - c0);
+    const int uraw = blockIdx.x * kThreads + threadIdx.x;
+    Columns<M> col;
+    make_columns<M>(col, g, min(uraw, g.units - 1), uraw < g.units);
+
+    const float *xp_b = xp + (size_t)b * g.C * g.plane;
+    const F4 *ip_b = FROM_CD ? nullptr : ip4 + (size_t)b * g.plane;
+    const float *cd_b = FROM_CD ? cd + (size_t)b * g.L * g.K : nullptr;
+    const float *dy_b = dy + (size_t)b * g.C * g.L;
+    const int ctr_off = g.p0 * g.Wp + g.p0;
+
+    float acc[CC][M], D[CC][M], dyv[CC][M];
+#pragma unroll
+    for (int cc = 0; cc < CC; ++cc)
+#pragma unroll
+        for (int n = 0; n < M; ++n) {
+            acc[cc][n] = 0.f;
+            float d = 0.f, xv = 0.f;
+            if (cc < nch && col.valid[n]) {
+                d = dy_b[(size_t)(c0 + cc) * g.L + col.lcl[n]];
+                xv = xp_b[(size_t)(c0 + cc) * g.plane + col.ibase[n] + ctr_off];
+            }
+            dyv[cc][n] = d;
+            D[cc][n] = d * xv;
+        }
+
+    BackwardSink<M> sink;
+    sink.dxp_b = dxp + (size_t)b * g.C * g.plane;
+    sink.D = D;
+    sink.valid = col.valid;
+    sink.W = g.W;
+    sink.gap = g.Wp - g.W;
+    sink.tpw = 0.f;
+    sink.tcw = 0.f;
+    sink.dcd_b = dcd ? dcd + (size_t)b * g.L * g.K : nullptr;
+    sink.lcl = col.lcl;
+    sink.K = g.K;
+    sink.cw = *col_w;
+    sink.dcd_atomic = gridDim.y > 1;
+
+    if constexpr (TAB_LDS)
+        window_sums<CC, M, FROM_CD>(acc, g, xp_b, ip_b, cd_b, lds_tab, *pos_w, *col_w, c0, nch, col, D, sink);
+    else
+        window_sums<CC, M, FROM_CD>(acc, g, xp_b, ip_b, cd_b, tab, *pos_w, *col_w, c0, nch, col, D, sink);
+
+    float *dxd_b = dxd + (size_t)b * g.C * g.L;
+#pragma unroll
+    for (int n = 0; n < M; ++n)
+        if (col.valid[n]) {
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc)
+                if (cc < nch) dxd_b[(size_t)(c0 + cc) * g.L + col.lcl[n]] = dyv[cc][n] * acc[cc][n];
+        }
+
+    // block reduction of the two parameter-gradient partial sums (fixed order: deterministic)
+    float tpw = sink.tpw, tcw = sink.tcw;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        tpw += __shfl_down(tpw, off, 64);
+        tcw += __shfl_down(tcw, off, 64);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[0][wave] = tpw; red[1][wave] = tcw; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, c = 0.f;
+        for (int i = 0; i < kThreads / 64; ++i) { a += red[0][i]; c += red[1][i]; }
+        const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partials[2 * blk] = a;
+        partials[2 * blk + 1] = c;
+    }
+}
+
+
+template <int CC, int M, bool FROM_CD, bool TAB_LDS>
+int launch_fwd(const GatherArgs &a, float *y, hipStream_t st)
+{
+    const Geom &g = a.g;
+    if (g.M != M) return MFL_ERR_INVALID_ARGUMENT;
+    const dim3 grid((g.units + kThreads - 1) / kThreads, (g.C + CC - 1) / CC, g.B);
+    const size_t lds = TAB_LDS ? (size_t)g.CK * 4 : 0;
+    hipLaunchKernelGGL((local_forward_kernel<CC, M, FROM_CD, TAB_LDS>), grid, dim3(kThreads), lds, st, g, a.xp, a.ip4,
+                       a.cd, a.tab, a.pos_w, a.col_w, y);
+    return (int)hipGetLastError();
+}
+
+template <int CC, int M, bool FROM_CD, bool TAB_LDS>
+int launch_bwd(const GatherArgs &a, const BackwardArgs &b, hipStream_t st)
+{
+    const Geom &g = a.g;
+    if (g.M != M) return MFL_ERR_INVALID_ARGUMENT;
+    const dim3 grid((g.units + kThreads - 1) / kThreads, (g.C + CC - 1) / CC, g.B);
+    const size_t lds = TAB_LDS ? (size_t)g.CK * 4 : 0;
+    hipLaunchKernelGGL((local_backward_kernel<CC, M, FROM_CD, TAB_LDS>), grid, dim3(kThreads), lds, st, g, a.xp, a.ip4,
+                       a.cd, a.tab, a.pos_w, a.col_w, b.dy, b.dxd, b.dxp, b.partials, b.dcd);
+    return (int)hipGetLastError();
+}
+
+template <int CC, int M, bool TAB_LDS>
+int launch_step(const GatherArgs &a, const StepArgs &s, hipStream_t st)
+{
+    const Geom &g = a.g;
+    if (g.M != M || g.C > CC) return MFL_ERR_INVALID_ARGUMENT;
+    const dim3 grid((g.units + kThreads - 1) / kThreads, 1, g.B);
+    const size_t lds = (TAB_LDS ? (size_t)((g.CK + 3) & ~3) * 4 : 0) + (size_t)g.C * g.C * 4;
+    hipLaunchKernelGGL((meanfield_step_kernel<CC, M, TAB_LDS>), grid, dim3(kThreads), lds, st, g, a.xp, a.ip4, a.tab,
+                       a.pos_w, a.col_w, s.unary, s.aw, s.ab, s.compat, s.logq, s.qp_out);
+    return (int)hipGetLastError();
+}
+
+// Pixels per thread the image-weight, LDS-table variants are built for at this width
+// (accumulator tile CC*M kept within the register budget).
+constexpr int kMaxM = (MFL_CC * 4 <= 96) ? 4 : 2;
+
+}  // namespace
+
+namespace mfl {
+
+#define MFL_CAT2(a, b) a##b
+#define MFL_CAT(a, b) MFL_CAT2(a, b)
+
+int MFL_CAT(launch_local_forward_cc, MFL_CC)(const GatherArgs &a, float *y, hipStream_t st)
+{
+    constexpr int CC = MFL_CC;
+    if (a.from_cd)   // caller-supplied tensor: compatibility path, one pixel per thread
+        return a.tab_lds ? launch_fwd<CC, 1, true, true>(a, y, st) : launch_fwd<CC, 1, true, false>(a, y, st);
+    if (!a.tab_lds) return launch_fwd<CC, 1, false, false>(a, y, st);
+    switch (a.g.M) {
+    case 1: return launch_fwd<CC, 1, false, true>(a, y, st);
+    case 2: return launch_fwd<CC, 2, false, true>(a, y, st);
+    case 4: if constexpr (kMaxM >= 4) return launch_fwd<CC, 4, false, true>(a, y, st);
+    }
+    return MFL_ERR_INVALID_ARGUMENT;
+}
+
+int MFL_CAT(launch_local_backward_cc, MFL_CC)(const GatherArgs &a, const BackwardArgs &b, hipStream_t st)
+{
+    constexpr int CC = MFL_CC;
+    if (a.from_cd)
+        return a.tab_lds ? launch_bwd<CC, 1, true, true>(a, b, st) : launch_bwd<CC, 1, true, false>(a, b, st);
+    if (!a.tab_lds) return launch_bwd<CC, 1, false, false>(a, b, st);
+    switch (a.g.M) {
+    case 1: return launch_bwd<CC, 1, false, true>(a, b, st);
+    case 2: return launch_bwd<CC, 2, false, true>(a, b, st);
+    }
+    return MFL_ERR_INVALID_ARGUMENT;
+}
+
+int MFL_CAT(launch_meanfield_step_cc, MFL_CC)(const GatherArgs &a, const StepArgs &s, hipStream_t st)
+{
+    constexpr int CC = MFL_CC;
+    if (!a.tab_lds) return launch_step<CC, 1, false>(a, s, st);
+    switch (a.g.M) {
+    case 1: return launch_step<CC, 1, true>(a, s, st);
+    case 2: return launch_step<CC, 2, true>(a, s, st);
+    case 4: if constexpr (kMaxM >= 4) return launch_step<CC, 4, true>(a, s, st);
+    }
+    return MFL_ERR_INVALID_ARGUMENT;
+}
+
+}  // namespace mfl

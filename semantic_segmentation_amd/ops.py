@@ -1,0 +1,114 @@
+"""Tensor-level wrappers of the C ABI (include/mfl.h): argument checking, workspace and
+output allocation through torch's caching allocator, launch on torch's current stream."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import lib, ptr, stream_of
+
+
+def _c(t):
+    return None if t is None else t.contiguous()
+
+
+def color_distance(image: torch.Tensor, k: int) -> torch.Tensor:
+    """[B,3,H,W] -> [B, H*W, k*k] squared colour distances (AdvancedModel.py:529-549)."""
+    _lib.require_device(image)
+    image = _c(image)
+    B, ch, H, W = image.shape
+    if ch != 3:
+        raise ValueError("the colour distance is defined for 3-channel images")
+    cd = torch.empty(B, H * W, k * k, dtype=torch.float32, device=image.device)
+    with torch.cuda.device(image.device):
+        _lib.check(lib.mfl_color_distance(ptr(image), ptr(cd), B, H, W, k, stream_of(image)), "mfl_color_distance")
+    return cd
+
+
+def local_forward(x, pos_w, col_w, k, image=None, cd=None) -> torch.Tensor:
+    """Conv2dLocal.forward (LocalConvolution.py:59-90); appearance term from `image` or a `cd` tensor."""
+    _lib.require_device(x, pos_w, col_w, image, cd)
+    x, image, cd = _c(x), _c(image), _c(cd)
+    B, C, H, W = x.shape
+    _check_appearance(B, H, W, k, image, cd)
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        ws = _lib.workspace(_lib.OP_LOCAL_FORWARD, B, C, H, W, k, 1, x.device)
+        _lib.check(lib.mfl_local_forward(ptr(x), ptr(image), ptr(cd), ptr(pos_w), ptr(col_w), ptr(y), B, C, H, W, k,
+                                         ptr(ws), ws.numel(), stream_of(x)), "mfl_local_forward")
+    return y
+
+
+def local_backward(x, pos_w, col_w, k, dy, image=None, cd=None, want_dcd=False):
+    """Returns (dx, dparams[2] = {d position_weight, d color_weight}, dcd or None)."""
+    _lib.require_device(x, pos_w, col_w, dy, image, cd)
+    x, dy, image, cd = _c(x), _c(dy), _c(image), _c(cd)
+    B, C, H, W = x.shape
+    _check_appearance(B, H, W, k, image, cd)
+    if dy.shape != x.shape:
+        raise RuntimeError(f"grad shape {tuple(dy.shape)} does not match input shape {tuple(x.shape)}")
+    dx = torch.empty_like(x)
+    dparams = torch.empty(2, dtype=torch.float32, device=x.device)
+    dcd = torch.empty_like(cd) if (want_dcd and cd is not None) else None
+    with torch.cuda.device(x.device):
+        ws = _lib.workspace(_lib.OP_LOCAL_BACKWARD, B, C, H, W, k, 1, x.device)
+        _lib.check(lib.mfl_local_backward(ptr(x), ptr(image), ptr(cd), ptr(pos_w), ptr(col_w), ptr(dy), ptr(dx),
+                                          ptr(dparams), ptr(dcd), B, C, H, W, k, ptr(ws), ws.numel(), stream_of(x)),
+                   "mfl_local_backward")
+    return dx, dparams, dcd
+
+
+def combine_forward(unary, smooth, mixtures=1, want_q=False):
+    """LogSoftmax(log_softmax(unary) - min over mixtures of smooth) (AdvancedModel.py:32-35, 242-244)."""
+    _lib.require_device(unary, smooth)
+    unary, smooth = _c(unary), _c(smooth)
+    B, C, H, W = unary.shape
+    if smooth.shape != (B, C * mixtures, H, W):
+        raise RuntimeError(f"smooth must be {(B, C * mixtures, H, W)}, got {tuple(smooth.shape)}")
+    logq = torch.empty_like(unary)
+    q = torch.empty_like(unary) if want_q else None
+    with torch.cuda.device(unary.device):
+        _lib.check(lib.mfl_combine_forward(ptr(unary), ptr(smooth), mixtures, ptr(logq), ptr(q), B, C, H, W,
+                                           stream_of(unary)), "mfl_combine_forward")
+    return (logq, q) if want_q else logq
+
+
+def meanfield_forward(unary, image, pos_w, col_w, k, iters, affine_w=None, affine_b=None, compat=None):
+    """`iters` fused mean-field updates; returns the final log-marginals [B,C,H,W]."""
+    _lib.require_device(unary, image, pos_w, col_w, affine_w, affine_b, compat)
+    unary, image, affine_w, affine_b, compat = _c(unary), _c(image), _c(affine_w), _c(affine_b), _c(compat)
+    B, C, H, W = unary.shape
+    _check_appearance(B, H, W, k, image, None)
+    if (affine_w is None) != (affine_b is None):
+        raise ValueError("affine_w and affine_b must be given together")
+    if affine_w is not None and (affine_w.numel() != C * H * W or affine_b.numel() != C * H * W):
+        raise RuntimeError("affine parameters must hold C*H*W elements")
+    if compat is not None and compat.shape != (C, C):
+        raise RuntimeError(f"compat must be {(C, C)}, got {tuple(compat.shape)}")
+    logq = torch.empty_like(unary)
+    with torch.cuda.device(unary.device):
+        ws = _lib.workspace(_lib.OP_MEANFIELD_FORWARD, B, C, H, W, k, iters, unary.device)
+        _lib.check(lib.mfl_meanfield_forward(ptr(unary), ptr(image), ptr(pos_w), ptr(col_w), ptr(affine_w),
+                                             ptr(affine_b), ptr(compat), ptr(logq), B, C, H, W, k, iters, ptr(ws),
+                                             ws.numel(), stream_of(unary)), "mfl_meanfield_forward")
+    return logq
+
+
+def argmax_labels(logq: torch.Tensor) -> torch.Tensor:
+    """uint8 label map [B,H,W] = argmax over channels (AdvancedModel.py:420-421)."""
+    _lib.require_device(logq)
+    logq = _c(logq)
+    B, C, H, W = logq.shape
+    labels = torch.empty(B, H, W, dtype=torch.uint8, device=logq.device)
+    with torch.cuda.device(logq.device):
+        _lib.check(lib.mfl_argmax_labels(ptr(logq), ptr(labels), B, C, H, W, stream_of(logq)), "mfl_argmax_labels")
+    return labels
+
+
+def _check_appearance(B, H, W, k, image, cd):
+    if (image is None) == (cd is None):
+        raise ValueError("exactly one of image / cd must be given")
+    if image is not None and image.shape != (B, 3, H, W):
+        raise RuntimeError(f"image must be {(B, 3, H, W)}, got {tuple(image.shape)}")
+    if cd is not None and cd.shape != (B, H * W, k * k):
+        raise RuntimeError(f"color distance tensor must be {(B, H * W, k * k)}, got {tuple(cd.shape)}")

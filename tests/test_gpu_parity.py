@@ -1,0 +1,271 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the reference's golden vectors.
+
+Bar: fp32 results within 1e-4 relative (conftest.assert_close: |a-e| <= 1e-4 * (|e| + max|e|)),
+and argmax label maps identical wherever the top-2 margin exceeds that tolerance.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, golden_files, load, rel_err
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def S():
+    import semantic_segmentation_amd as S
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return S
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def scalar(v):
+    return torch.tensor([float(v)], dtype=torch.float32, device="cuda")
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------ golden vectors
+@pytest.mark.parametrize("path", golden_files("cd"))
+def test_color_distance_golden(path, S):
+    d = load(path)
+    cd = host(S.ops.color_distance(dev(d["img"]), int(d["k"])))
+    assert_close(cd, d["cd"], RTOL, "cd")
+
+
+@pytest.mark.parametrize("path", golden_files("local"))
+def test_local_golden_tensor_mode(path, S):
+    """Conv2dLocal with the golden's own (random) colour-distance tensor: forward and all gradients."""
+    d = load(path)
+    k = int(d["k"])
+    x, cd, dy = dev(d["x"]), dev(d["cd"]), dev(d["dy"])
+    pw, cw = scalar(d["pw"]), scalar(d["cw"])
+    y = S.ops.local_forward(x, pw, cw, k, cd=cd)
+    assert_close(host(y), d["y"], RTOL, "y")
+    dx, dpar, _ = S.ops.local_backward(x, pw, cw, k, dy, cd=cd)
+    assert_close(host(dx), d["dx"], RTOL, "dx")
+    dpar = host(dpar)
+    for got, key in ((dpar[0], "dpw64"), (dpar[1], "dcw64")):
+        ref = float(d[key][0])
+        assert abs(got - ref) <= RTOL * abs(ref) + 1e-6, (key, got, ref)
+
+
+@pytest.mark.parametrize("path", golden_files("meanfield"))
+def test_meanfield_golden(path, S):
+    d = load(path)
+    k = int(d["k"])
+    aw = dev(d["la_w"]) if "la_w" in d else None
+    ab = dev(d["la_b"]) if "la_b" in d else None
+    for it in (1, 2, 5, 10):
+        lq = S.ops.meanfield_forward(dev(d["unary"]), dev(d["img"]), scalar(d["pw"]), scalar(d["cw"]), k, it,
+                                     aw, ab, dev(d["compat"]))
+        assert_close(host(lq), d[f"logq_it{it}"], RTOL, f"logq it{it}")
+
+
+def test_dpn_phase2_and_combine_golden(S):
+    """DPNModel.forward phase 2 / phase 4 data flow with the reference's own 50x50 window."""
+    d = load(golden_files("dpn")[0])
+    k, M = int(d["k"]), int(d["mixtures"])
+    unary, img = dev(d["unary"]), dev(d["img"])
+    msg = S.ops.local_forward(unary, scalar(d["pw"]), scalar(d["cw"]), k, image=img)
+    a = dev(d["la_w"]) * msg + dev(d["la_b"])
+    assert_close(host(torch.log_softmax(a, dim=1)), d["phase2"], RTOL, "phase2")
+    c = dev(d["ga_w"]) * torch.nn.functional.conv2d(a, dev(d["conv_w"]), dev(d["conv_b"]), padding=4) + dev(d["ga_b"])
+    out = S.ops.combine_forward(unary, c, mixtures=M)
+    assert_close(host(out), d["phase4"], 2e-4, "phase4")   # includes MIOpen's 9x9 convolution
+
+
+def test_tail_golden(S):
+    d = load(golden_files("tail")[0])
+    out, q = S.ops.combine_forward(dev(d["unary"]), dev(d["c"]), mixtures=int(d["mixtures"]), want_q=True)
+    assert_close(host(out), d["out"], RTOL, "combine")
+    assert_close(host(q), np.exp(d["out"]), RTOL, "q")
+
+
+# ------------------------------------------------------------------ seeded inputs vs the oracle
+SHAPES = [  # B, C, H, W, k
+    (1, 2, 128, 128, 3),       # BASELINE config 1 shape (2 labels, 128^2)
+    (2, 21, 48, 64, 7),        # 21 labels, 7x7 (configs 2/3, reduced image)
+    (1, 19, 40, 96, 11),       # 19 labels, 11x11 (config 4, reduced image)
+    (1, 40, 24, 24, 7),        # channel chunks: 40 = 32 + 8
+    (1, 150, 16, 16, 7),       # 150 labels (config 5, reduced image)
+    (1, 5, 33, 17, 4),         # even window, odd sizes
+    (2, 3, 1, 1, 3),           # a single pixel
+    (1, 7, 9, 300, 5),         # wide and short
+    (1, 21, 64, 64, 50),       # the model's own configuration (offset table in global memory)
+    (1, 4, 31, 29, 1),         # 1x1 window
+]
+
+
+def make_inputs(shape, seed=0):
+    B, C, H, W, k = shape
+    rng = np.random.default_rng(1234 + seed)
+    x = (2 * rng.standard_normal((B, C, H, W))).astype(np.float32)
+    mean = np.array([0.485, 0.456, 0.406], np.float32).reshape(1, 3, 1, 1)
+    std = np.array([0.229, 0.224, 0.225], np.float32).reshape(1, 3, 1, 1)
+    img = ((rng.random((B, 3, H, W), dtype=np.float32) - mean) / std).astype(np.float32)
+    dy = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    return x, img, dy
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("weights", [(-0.004, -0.003), (0.3, -0.7)])
+def test_local_forward_backward_vs_oracle(shape, weights, S, oracle):
+    B, C, H, W, k = shape
+    pw, cw = weights
+    x, img, dy = make_inputs(shape)
+    y = S.ops.local_forward(dev(x), scalar(pw), scalar(cw), k, image=dev(img))
+    assert_close(host(y), oracle.local_forward(x, pw, cw, k, img=img), RTOL, "y")
+    dx, dpar, _ = S.ops.local_backward(dev(x), scalar(pw), scalar(cw), k, dev(dy), image=dev(img))
+    rdx, rdpw, rdcw = oracle.local_backward(x, pw, cw, k, dy, img=img)
+    assert_close(host(dx), rdx, RTOL, "dx")
+    dpar = host(dpar)
+    assert abs(dpar[0] - rdpw) <= 2e-4 * abs(rdpw) + 1e-5, (dpar[0], rdpw)
+    assert abs(dpar[1] - rdcw) <= 2e-4 * abs(rdcw) + 1e-5, (dpar[1], rdcw)
+
+
+@pytest.mark.parametrize("shape", SHAPES[:6])
+def test_tensor_mode_equals_image_mode(shape, S):
+    """A materialised colour-distance tensor gives the same result as the fused recomputation."""
+    B, C, H, W, k = shape
+    x, img, dy = make_inputs(shape, 1)
+    pw, cw = scalar(0.3), scalar(-0.7)
+    cd = S.ops.color_distance(dev(img), k)
+    a = S.ops.local_forward(dev(x), pw, cw, k, image=dev(img))
+    b = S.ops.local_forward(dev(x), pw, cw, k, cd=cd)
+    assert_close(host(b), host(a), 1e-5, "tensor vs image mode")
+    dxa, dpa, _ = S.ops.local_backward(dev(x), pw, cw, k, dev(dy), image=dev(img))
+    dxb, dpb, dcd = S.ops.local_backward(dev(x), pw, cw, k, dev(dy), cd=cd, want_dcd=True)
+    assert_close(host(dxb), host(dxa), 1e-5, "dx")
+    assert_close(host(dpb), host(dpa), 1e-4, "dparams")
+    # d cd = cw * sum_c D * S, so sum(cd * dcd) / cw = d cw
+    got = float((cd.double() * dcd.double()).sum() / -0.7)
+    assert abs(got - float(dpb[1])) <= 1e-4 * abs(float(dpb[1])) + 1e-5
+
+
+@pytest.mark.parametrize("shape", [SHAPES[0], SHAPES[1], SHAPES[2], SHAPES[3], SHAPES[5]])
+@pytest.mark.parametrize("mode", ["plain", "compat", "affine+compat"])
+def test_meanfield_vs_oracle(shape, mode, S, oracle):
+    B, C, H, W, k = shape
+    unary, img, _ = make_inputs(shape, 2)
+    rng = np.random.default_rng(7)
+    compat = ((1 - np.eye(C)) + 0.01 * rng.standard_normal((C, C))).astype(np.float32) if "compat" in mode else None
+    aw = (1 + 0.2 * rng.standard_normal((1, C, H, W))).astype(np.float32) if "affine" in mode else None
+    ab = (0.1 * rng.standard_normal((1, C, H, W))).astype(np.float32) if "affine" in mode else None
+    opt = lambda a: None if a is None else dev(a)
+    for iters in (1, 5):
+        lq = host(S.ops.meanfield_forward(dev(unary), dev(img), scalar(-0.004), scalar(-0.003), k, iters,
+                                          opt(aw), opt(ab), opt(compat)))
+        ref = oracle.meanfield_forward(unary, img, -0.004, -0.003, k, iters, aw, ab, compat)
+        assert_close(lq, ref, RTOL, f"logq {mode} iters={iters}")
+        assert np.allclose(np.exp(lq.astype(np.float64)).sum(1), 1.0, atol=1e-5)
+        # label maps: identical wherever the top-2 margin exceeds the tolerance
+        labels = host(S.ops.argmax_labels(dev(lq)))
+        srt = np.sort(ref, axis=1)
+        decided = (srt[:, -1] - srt[:, -2]) > RTOL * (1 + np.abs(srt[:, -1]))
+        assert (labels[decided] == ref.argmax(1)[decided]).all()
+        assert decided.mean() > 0.5
+
+
+def test_150_labels_meanfield_vs_oracle(S, oracle):
+    """Large-label configuration: unfused path (gather in channel chunks, LxL transform, normalise)."""
+    shape = (1, 150, 12, 14, 7)
+    unary, img, _ = make_inputs(shape, 3)
+    rng = np.random.default_rng(8)
+    compat = ((1 - np.eye(150)) * 0.05 + 0.01 * rng.standard_normal((150, 150))).astype(np.float32)
+    lq = host(S.ops.meanfield_forward(dev(unary), dev(img), scalar(-0.004), scalar(-0.003), 7, 3, None, None,
+                                      dev(compat)))
+    assert_close(lq, oracle.meanfield_forward(unary, img, -0.004, -0.003, 7, 3, None, None, compat), RTOL, "logq")
+
+
+# ------------------------------------------------------------------ full BASELINE sizes: properties + spot checks
+def test_config2_full_size_properties(S, oracle):
+    """21 labels, 512x512, batch 8, 7x7 (BASELINE config 2), at full size:
+    - one image against the oracle (forward of the local operator and 2 mean-field iterations),
+    - batch independence: image b of the batch equals the same image run alone (the sharding premise),
+    - the operator is bilinear in (weights, x^2): y(a*pw, a*cw) = a*y and y(s*x) = s^2 * y,
+    - marginals sum to one."""
+    shape = (8, 21, 512, 512, 7)
+    unary, img, _ = make_inputs(shape, 4)
+    pw, cw = scalar(-0.004), scalar(-0.003)
+    U, I = dev(unary), dev(img)
+    y = S.ops.local_forward(U, pw, cw, 7, image=I)
+    ref = oracle.local_forward(unary[3:4], -0.004, -0.003, 7, img=img[3:4])
+    assert_close(host(y[3:4]), ref, RTOL, "y[3]")
+    alone = S.ops.local_forward(U[5:6].contiguous(), pw, cw, 7, image=I[5:6].contiguous())
+    assert torch.equal(alone, y[5:6])
+    y2 = S.ops.local_forward(U, scalar(-0.008), scalar(-0.006), 7, image=I)
+    assert_close(host(y2[0]), 2 * host(y[0]), 1e-5, "linear in the weights")
+    y3 = S.ops.local_forward(U * 0.5, pw, cw, 7, image=I)
+    assert_close(host(y3[1]), 0.25 * host(y[1]), 1e-5, "quadratic in x")
+    compat = dev(((1 - np.eye(21)) + 0.01 * np.random.default_rng(5).standard_normal((21, 21))).astype(np.float32))
+    lq = S.ops.meanfield_forward(U, I, pw, cw, 7, 2, None, None, compat)
+    refq = oracle.meanfield_forward(unary[6:7], img[6:7], -0.004, -0.003, 7, 2, None, None, host(compat))
+    assert_close(host(lq[6:7]), refq, RTOL, "logq[6]")
+    assert torch.allclose(torch.exp(lq.double()).sum(1), torch.ones(8, 512, 512, dtype=torch.float64, device="cuda"),
+                          atol=1e-5)
+
+
+def test_config4_shape_properties(S, oracle):
+    """19 labels, 1024x2048, 11x11 (BASELINE config 4) at full image size, batch 2 (one GPU's share
+    at 8 GPUs): a 64-row band of the first image against... the whole image is needed by the
+    scrambled gather, so the oracle runs one full image once (about 20 s of CPU)."""
+    shape = (2, 19, 1024, 2048, 11)
+    unary, img, _ = make_inputs(shape, 5)
+    pw, cw = scalar(-0.004), scalar(-0.003)
+    y = S.ops.local_forward(dev(unary), pw, cw, 11, image=dev(img))
+    ref = oracle.local_forward(unary[1:2], -0.004, -0.003, 11, img=img[1:2])
+    assert_close(host(y[1:2]), ref, RTOL, "y[1]")
+    alone = S.ops.local_forward(dev(unary[0:1]), pw, cw, 11, image=dev(img[0:1]))
+    assert torch.equal(alone, y[0:1])
+
+
+# ------------------------------------------------------------------ the drop-in module
+def test_module_forward_backward_like_reference(S, oracle):
+    """Conv2dLocal + color_distance used exactly as DPNModel uses them (AdvancedModel.py:135-137, 216-222)."""
+    shape = (2, 21, 32, 40, 7)
+    B, C, H, W, k = shape
+    x, img, dy = make_inputs(shape, 6)
+    calc = S.color_distance(kernel_size=(k, k), channels=3)
+    layer = S.Conv2dLocal(in_height=H, in_width=W, channels=C, kernel_size=(k, k)).cuda()
+    with torch.no_grad():
+        layer.position_weight.fill_(0.3)
+        layer.color_weight.fill_(-0.7)
+    xt = dev(x).requires_grad_(True)
+    out = layer(xt, calc(dev(img)))
+    out.backward(dev(dy))
+    rdx, rdpw, rdcw = oracle.local_backward(x, 0.3, -0.7, k, dy, img=img)
+    assert_close(host(out), oracle.local_forward(x, 0.3, -0.7, k, img=img), RTOL, "module forward")
+    assert_close(host(xt.grad), rdx, RTOL, "module dx")
+    assert abs(layer.position_weight.grad.item() - rdpw) <= 2e-4 * abs(rdpw)
+    assert abs(layer.color_weight.grad.item() - rdcw) <= 2e-4 * abs(rdcw)
+    # tensor form, as the reference passes it
+    out2 = layer(dev(x), calc(dev(img)).materialize())
+    assert_close(host(out2), host(out), 1e-5, "tensor form")
+
+
+def test_meanfield_module_grad_path_matches_fused(S):
+    """With gradients enabled the module composes the loop from the HIP local operator and torch ops;
+    it must agree with the fused inference loop."""
+    B, C, H, W, k = 2, 5, 20, 24, 3
+    unary, img, _ = make_inputs((B, C, H, W, k), 7)
+    mod = S.MeanFieldLocal(H, W, C, k, iters=3, compat=True, affine=True).cuda()
+    with torch.no_grad():
+        mod.local_convolution_layer.position_weight.fill_(-0.004)
+        mod.local_convolution_layer.color_weight.fill_(-0.003)
+        fused = mod(dev(unary), dev(img))
+    U = dev(unary).requires_grad_(True)
+    composed = mod(U, dev(img))
+    assert_close(host(composed), host(fused), RTOL, "composed vs fused")
+    loss = torch.nn.functional.nll_loss(composed, torch.randint(0, C, (B, H, W), device="cuda"))
+    loss.backward()
+    for p in list(mod.parameters()) + [U]:
+        assert p.grad is not None and torch.isfinite(p.grad).all()

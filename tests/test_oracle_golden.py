@@ -1,0 +1,100 @@
+"""The oracle (numpy and C restatements) against golden vectors produced by the imported reference."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, golden_files, load, rel_err
+from oracle import ref_numpy as R
+
+# fp64 goldens pin formulas and index maps (an index error is an O(1) difference); the residue
+# is the reference's float32 parameters.  fp32 goldens are what the reference outputs as shipped.
+TIGHT = 2e-6
+FP32 = 2e-5
+
+
+@pytest.mark.parametrize("path", golden_files("cd"))
+def test_color_distance(path, oracle):
+    d = load(path)
+    k = int(d["k"])
+    assert rel_err(R.color_distance(d["img"], k), d["cd64"]) < 1e-12
+    assert rel_err(oracle.color_distance(d["img"], k), d["cd"]) < FP32
+    # centre tap is exactly zero (AdvancedModel.py:547)
+    centre = (k // 2) * k + k // 2
+    assert (oracle.color_distance(d["img"], k)[:, :, centre] == 0).all()
+
+
+@pytest.mark.parametrize("path", golden_files("local"))
+def test_local_forward_backward(path, oracle):
+    d = load(path)
+    k, pw, cw = int(d["k"]), float(d["pw"]), float(d["cw"])
+    assert (R.position_distances(k) == d["pd"]).all()
+    assert R.position_distances(k).dtype == np.int64
+    y = R.local_forward(d["x"], d["cd"], d["pw"], d["cw"], k)
+    dx, dpw, dcw = R.local_backward(d["x"], d["cd"], d["pw"], d["cw"], k, d["dy"])
+    assert rel_err(y, d["y64"]) < TIGHT and rel_err(dx, d["dx64"]) < TIGHT
+    yc = oracle.local_forward(d["x"], pw, cw, k, cd=d["cd"])
+    dxc, dpwc, dcwc = oracle.local_backward(d["x"], pw, cw, k, d["dy"], cd=d["cd"])
+    assert rel_err(yc, d["y64"]) < TIGHT and rel_err(dxc, d["dx64"]) < TIGHT
+    assert rel_err(yc, d["y"]) < FP32 and rel_err(dxc, d["dx"]) < FP32
+    for got, got_c, key in ((dpw, dpwc, "dpw"), (dcw, dcwc, "dcw")):
+        ref64, ref32 = float(d[key + "64"][0]), float(d[key][0])
+        scale = abs(ref64) + 1e-6
+        assert abs(got - ref64) / scale < TIGHT and abs(got_c - ref64) / scale < TIGHT
+        assert abs(got_c - ref32) / scale < 1e-4
+
+
+def test_tail(oracle):
+    d = load(golden_files("tail")[0])
+    M = int(d["mixtures"])
+    a = R.linear_activation(d["t"], d["la_w"], d["la_b"])
+    assert rel_err(a, d["a"]) < FP32
+    assert rel_err(R.block_min_pooling(d["c"], M), d["smooth"]) == 0
+    assert rel_err(R.combine(d["unary"], d["smooth"]), d["out"]) < FP32
+    assert rel_err(oracle.combine(d["unary"], d["c"], M), d["out"]) < FP32
+    logq, q = oracle.combine(d["unary"], d["smooth"], 1, want_q=True)
+    assert rel_err(logq, d["out"]) < FP32 and rel_err(q, np.exp(d["out"])) < FP32
+
+
+def test_dpn_phases(oracle):
+    """DPNModel.forward phases 2-4 (unary CNN bypassed) = oracle local op + affine (+ stock 9x9 conv,
+    which is outside the path, + min-pool + combine).  The model's window is 50x50."""
+    d = load(golden_files("dpn")[0])
+    k, M = int(d["k"]), int(d["mixtures"])
+    assert (R.position_distances(k) == d["pd"]).all()
+    msg = oracle.local_forward(d["unary"], float(d["pw"]), float(d["cw"]), k, img=d["img"])
+    a = R.linear_activation(msg.astype(np.float64), d["la_w"], d["la_b"])
+    assert rel_err(R.log_softmax(a, 1), d["phase2"]) < FP32
+    conv = torch.nn.functional.conv2d(torch.from_numpy(a), torch.from_numpy(d["conv_w"]).double(),
+                                      torch.from_numpy(d["conv_b"]).double(), padding=4).numpy()
+    c = R.linear_activation(conv, d["ga_w"], d["ga_b"])
+    smooth = R.block_min_pooling(c, M)
+    assert rel_err(R.log_softmax(smooth, 1), d["phase3"]) < FP32
+    assert rel_err(R.combine(d["unary"].astype(np.float64), smooth), d["phase4"]) < FP32
+    assert rel_err(oracle.combine(d["unary"], c.astype(np.float32), M), d["phase4"]) < FP32
+
+
+@pytest.mark.parametrize("path", golden_files("meanfield"))
+def test_meanfield(path, oracle):
+    d = load(path)
+    k, pw, cw = int(d["k"]), float(d["pw"]), float(d["cw"])
+    aw, ab = d.get("la_w"), d.get("la_b")
+    logs = R.meanfield_forward(d["unary"], d["img"], d["pw"], d["cw"], k, 10, aw, ab, d["compat"], return_all=True)
+    for it in (1, 2, 5, 10):
+        assert rel_err(logs[it - 1], d[f"logq64_it{it}"]) < TIGHT
+        c = oracle.meanfield_forward(d["unary"], d["img"], pw, cw, k, it, aw, ab, d["compat"])
+        assert rel_err(c, d[f"logq64_it{it}"]) < TIGHT
+        assert rel_err(c, d[f"logq_it{it}"]) < FP32
+        assert np.allclose(np.exp(c.astype(np.float64)).sum(axis=1), 1.0, atol=1e-5)
+
+
+def test_image_mode_equals_tensor_mode(oracle):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 5, 9, 7), dtype=np.float32)
+    img = rng.standard_normal((2, 3, 9, 7), dtype=np.float32)
+    dy = rng.standard_normal((2, 5, 9, 7), dtype=np.float32)
+    cd = oracle.color_distance(img, 4)
+    assert np.array_equal(oracle.local_forward(x, 0.3, -0.7, 4, img=img), oracle.local_forward(x, 0.3, -0.7, 4, cd=cd))
+    a, b = oracle.local_backward(x, 0.3, -0.7, 4, dy, img=img), oracle.local_backward(x, 0.3, -0.7, 4, dy, cd=cd)
+    assert np.array_equal(a[0], b[0])
+    # the OpenMP reduction order of the two scalar sums is not fixed: equal to double rounding
+    assert np.allclose(a[1:], b[1:], rtol=1e-12)
