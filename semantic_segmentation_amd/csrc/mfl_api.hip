@@ -257,7 +257,7 @@ size_t padded_floats(const Geom &g) { return (size_t)g.B * g.C * g.plane + padde
 
 int backward_blocks(const Geom &g, int cc)
 {
-    return ((g.units + kThreads - 1) / kThreads) * ((g.C + cc - 1) / cc) * g.B;
+    return blocks_per_image(g) * ((g.C + cc - 1) / cc) * g.B;
 }
 
 Workspace carve(int op, const Geom &g, int cc)

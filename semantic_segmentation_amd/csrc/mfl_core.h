@@ -19,8 +19,8 @@
 // SAME (c', t') of M horizontally consecutive source pixels l', l'+1, ...,
 // i.e. M consecutive floats of one padded row (unless the run crosses the end
 // of an image row).  One address decode therefore serves M gathers, and the
-// gathers are one M-wide load.  "Units" number the (tile, t_0) pairs:
-//     unit u -> tile i = u / CK, t_0 = u % CK, l_0 = i*M*CK + t_0.
+// gathers are one M-wide load.  A "unit" is a (tile i, t_0) pair, t_0 < CK:
+//     l_0 = i*M*CK + t_0;  units are laid out over lanes, waves and blocks by make_columns.
 //
 // ---- incremental decode ------------------------------------------------------
 // Per thread the decode state of row j is (r, y', x') with g_0 = l'*CK + r,
@@ -29,8 +29,9 @@
 // carries only; host-computed constants:
 //     L   = q *CK + rho,   q  = dqy*W + dqx       (tap step)
 //     K*L = qK*CK + rhoK,  qK = dKy*W + dKx       (channel step)
-// The address of the run is  y'*Wp + x' + tab[r]  in the padded plane set of
-// the image, tab[r] = c'*plane + (t'/k)*Wp + t'%k  (a CK-entry table).
+// The address of the run is  (y'*Wp + x') + tab[r]  in the padded plane set of
+// the image, tab[r] = c'*plane + (t'/k)*Wp + t'%k  (a CK-entry table); the
+// thread carries y'*Wp + x' as one linear offset plus x' for the row wrap.
 #ifndef MFL_CORE_H
 #define MFL_CORE_H
 
@@ -113,40 +114,50 @@ MFL_HD int table_entry(const Geom &g, int r)
     return cp * g.plane + ky * g.Wp + kx;
 }
 
-// Load the M floats of a run starting at p whose first source pixel has column
-// x in an image row of W pixels; a run that crosses the row end continues
-// `gap` = Wp - W floats later (first pixel of the next padded row).
+// Wide load of the M consecutive floats of a run (no row crossing).
 template <int M>
-MFL_D void load_run(float (&v)[M], const float *p, int x, int W, int gap)
+MFL_D void load_run(float (&v)[M], const float *p)
 {
     if constexpr (M == 1) {
         v[0] = p[0];
+    } else if constexpr (M == 2) {
+        const f2u t = *reinterpret_cast<const f2u *>(p);
+        v[0] = t.x; v[1] = t.y;
     } else {
-        const bool crosses = (x + M > W);
-#if defined(__HIP_DEVICE_COMPILE__)
-        const bool any_cross = __builtin_amdgcn_ballot_w64(crosses) != 0;   // wave-uniform branch
-#else
-        const bool any_cross = crosses;
-#endif
-        if (!any_cross) {
-            if constexpr (M == 2) {
-                const f2u t = *reinterpret_cast<const f2u *>(p);
-                v[0] = t.x; v[1] = t.y;
-            } else {
 #pragma unroll
-                for (int n = 0; n < M; n += 4) {
-                    const f4u t = *reinterpret_cast<const f4u *>(p + n);
-                    v[n] = t.x; v[n + 1] = t.y; v[n + 2] = t.z; v[n + 3] = t.w;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int n = 0; n < M; ++n) v[n] = p[n + ((x + n >= W) ? gap : 0)];
+        for (int n = 0; n < M; n += 4) {
+            const f4u t = *reinterpret_cast<const f4u *>(p + n);
+            v[n] = t.x; v[n + 1] = t.y; v[n + 2] = t.z; v[n + 3] = t.w;
         }
     }
 }
 
-// Per-thread column set of unit u (see header comment).
+MFL_D bool wave_any(bool pred)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(pred) != 0;   // wave-uniform
+#else
+    return pred;
+#endif
+}
+
+// ---- thread -> (tile, t_0) mapping --------------------------------------------
+// A wave's 64 lanes cover kWaveTiles consecutive tiles x kWaveR consecutive t_0.  Lanes of
+// consecutive tiles gather from consecutive groups of M source pixels and lanes of
+// consecutive t_0 from consecutive taps of the same padded row, so one wave-wide gather
+// reads a few contiguous row pieces of about M*kWaveTiles + k floats instead of 64/k short
+// ones.  The 4 waves of a 256-thread block take consecutive t_0 groups of the same tiles.
+constexpr int kWaveTiles = 4;
+constexpr int kWaveR = 64 / kWaveTiles;
+constexpr int kBlockWaves = 4;
+constexpr int kBlockR = kWaveR * kBlockWaves;
+
+MFL_HD int blocks_per_image(const Geom &g)
+{
+    return ((g.ntile + kWaveTiles - 1) / kWaveTiles) * ((g.CK + kBlockR - 1) / kBlockR);
+}
+
+// Per-thread column set (see header comment).
 template <int M>
 struct Columns {
     int l0;          // first column, clamped into [0, L)
@@ -155,16 +166,24 @@ struct Columns {
     bool valid[M];   // column n exists and this thread is not a grid-tail duplicate
 };
 
+// block = blockIdx.x within the image, tid = threadIdx.x (0..255)
 template <int M>
-MFL_D void make_columns(Columns<M> &col, const Geom &g, int unit, bool thread_active)
+MFL_D void make_columns(Columns<M> &col, const Geom &g, int block, int tid)
 {
-    const int i = unit / g.CK, t0 = unit - i * g.CK;
+    const int nrg = (g.CK + kBlockR - 1) / kBlockR;
+    const int tg = block / nrg, rg = block - tg * nrg;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int i_raw = tg * kWaveTiles + lane / kWaveR;
+    const int t_raw = rg * kBlockR + wave * kWaveR + (lane % kWaveR);
+    const bool active = i_raw < g.ntile && t_raw < g.CK;
+    const int i = i_raw < g.ntile ? i_raw : g.ntile - 1;
+    const int t0 = t_raw < g.CK ? t_raw : g.CK - 1;
     const int l0 = i * (M * g.CK) + t0;
     col.l0 = l0 < g.L ? l0 : g.L - 1;
 #pragma unroll
     for (int n = 0; n < M; ++n) {
         const int ln = l0 + n * g.CK;
-        col.valid[n] = thread_active && ln < g.L;
+        col.valid[n] = active && ln < g.L;
         const int lc = ln < g.L ? ln : g.L - 1;
         const int y = lc / g.W;
         col.lcl[n] = lc;
@@ -184,17 +203,24 @@ struct NoSink {
     static constexpr bool enabled = false;
 };
 
-template <int CC, int M, bool FROM_CD, class TabPtr, class Sink>
+// Channels gathered per batch: all addresses of a batch are formed first, then all its loads are
+// issued back to back, then the FMAs.  Straight-line phases keep a batch's loads in flight together.
+MFL_HD constexpr int batch_width(int CC, int M) { return M >= 4 ? (CC < 7 ? CC : 7) : (CC < 8 ? CC : 8); }
+
+template <int CC, int M, bool FROM_CD, bool EXACT, class TabPtr, class Sink>
 MFL_D void window_sums(float (&acc)[CC][M], const Geom &g, const float *__restrict__ xp_b,
                        const F4 *__restrict__ ip_b, const float *__restrict__ cd_b, TabPtr tab, float pw, float cw,
                        int c0, int nch, const Columns<M> &col, const float (*dmul)[M], Sink &sink)
 {
+    constexpr int CB = batch_width(CC, M);
     const int tmp = c0 * g.rhoK + col.l0;
-    const int lp = c0 * g.qK + tmp / g.CK;
+    const int lp0 = c0 * g.qK + tmp / g.CK;
+    const int W = g.W, gap = g.Wp - g.W;
+    // decode state of (channel c0, tap t): table index rs, source column xs, padded offset ls = y'*Wp + x'
     int rs = tmp % g.CK;
-    int ys = lp / g.W;
-    int xs = lp - ys * g.W;
-    const int gap = g.Wp - g.W;
+    int xs = lp0 % W;
+    int ls = (lp0 / W) * g.Wp + xs;
+    const int dq_lin = g.dqy * g.Wp + g.dqx, dK_lin = g.dKy * g.Wp + g.dKx;
 
     F4 ctr[M];
     if constexpr (!FROM_CD) {
@@ -225,38 +251,74 @@ MFL_D void window_sums(float (&acc)[CC][M], const Geom &g, const float *__restri
 #pragma unroll
             for (int n = 0; n < M; ++n) u[n] = 0.0f;
 
-            int r = rs, y = ys, x = xs;
+            int r = rs, x = xs, lin = ls;
+            int a_first = 0;
 #pragma unroll
-            for (int cc = 0; cc < CC; ++cc) {
-                if (cc < nch) {
-                    const int a = y * g.Wp + x + tab[r];
-                    float v[M];
-                    load_run<M>(v, xp_b + a, x, g.W, gap);
+            for (int cb = 0; cb < CC; cb += CB) {
+                int a[CB], xc[CB];
+                bool cross = false;
+                // phase A: addresses (and the decode step to the next channel)
 #pragma unroll
-                    for (int n = 0; n < M; ++n) acc[cc][n] = fmaf(w[n], v[n], acc[cc][n]);
-                    if constexpr (Sink::enabled) {
-#pragma unroll
-                        for (int n = 0; n < M; ++n) u[n] = fmaf(dmul[cc][n], v[n], u[n]);
-                        sink.scatter(a, x, cc, w);
+                for (int i = 0; i < CB; ++i) {
+                    if (cb + i < CC) {
+                        int ai = lin + tab[r];
+                        if (cb + i == 0) a_first = ai;
+                        if constexpr (!EXACT) ai = (cb + i < nch) ? ai : a_first;   // channels past the chunk: a valid dummy
+                        a[i] = ai;
+                        xc[i] = x;
+                        if constexpr (M > 1) cross |= (x + M > W);
+                        r += g.rhoK;
+                        const int carry = r >= g.CK;
+                        r -= carry ? g.CK : 0;
+                        x += g.dKx + carry;
+                        const int wrap = x >= W;
+                        x -= wrap ? W : 0;
+                        lin += dK_lin + carry + (wrap ? gap : 0);
                     }
-                    r += g.rhoK;
-                    const int carry = r >= g.CK;
-                    r -= carry ? g.CK : 0;
-                    x += g.dKx + carry;
-                    const int wrap = x >= g.W;
-                    x -= wrap ? g.W : 0;
-                    y += g.dKy + wrap;
                 }
+                // phase B: the batch's loads.  A run that crosses the end of an image row continues
+                // `gap` floats later; that is rare, so ONE wave-uniform branch per batch selects between
+                // the all-wide form and a form in which the crossing lanes load their floats one by one.
+                float v[CB][M];
+                if (M == 1 || !wave_any(cross)) {
+#pragma unroll
+                    for (int i = 0; i < CB; ++i)
+                        if (cb + i < CC) load_run<M>(v[i], xp_b + a[i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < CB; ++i)
+                        if (cb + i < CC) {
+                            if (xc[i] + M > W) {
+#pragma unroll
+                                for (int n = 0; n < M; ++n) v[i][n] = xp_b[a[i] + n + ((xc[i] + n >= W) ? gap : 0)];
+                            } else {
+                                load_run<M>(v[i], xp_b + a[i]);
+                            }
+                        }
+                }
+                // phase D: accumulate
+#pragma unroll
+                for (int i = 0; i < CB; ++i)
+                    if (cb + i < CC) {
+#pragma unroll
+                        for (int n = 0; n < M; ++n) acc[cb + i][n] = fmaf(w[n], v[i][n], acc[cb + i][n]);
+                        if constexpr (Sink::enabled) {
+#pragma unroll
+                            for (int n = 0; n < M; ++n) u[n] = fmaf(dmul[cb + i][n], v[i][n], u[n]);
+                            if (EXACT || cb + i < nch) sink.scatter(a[i], xc[i], cb + i, w);
+                        }
+                    }
             }
             if constexpr (Sink::enabled) sink.tap(t, pd, cdv, u);
 
+            // decode step to the next tap
             rs += g.rho;
             const int carry = rs >= g.CK;
             rs -= carry ? g.CK : 0;
             xs += g.dqx + carry;
-            const int wrap = xs >= g.W;
-            xs -= wrap ? g.W : 0;
-            ys += g.dqy + wrap;
+            const int wrap = xs >= W;
+            xs -= wrap ? W : 0;
+            ls += dq_lin + carry + (wrap ? gap : 0);
         }
     }
 }

@@ -1,5 +1,6 @@
 // Gather kernels of the local-window message-passing library (gfx950), one
-// translation unit per channel-chunk width: compile with -DMFL_CC=<8|19|21|32>.
+// translation unit per (channel-chunk width, kernel kind): compile with -DMFL_CC=<8|19|21|32>
+// -DMFL_KIND=<1 forward | 2 backward | 3 fused mean-field step>.
 // Thread mapping, index map and incremental decode: mfl_core.h.  Data layout and
 // the C ABI: mfl_api.hip, include/mfl.h.
 #include <hip/hip_runtime.h>
@@ -8,8 +9,8 @@
 #include "../../include/mfl.h"
 #include "mfl_gather.h"
 
-#ifndef MFL_CC
-#error "compile with -DMFL_CC=<channel chunk width>"
+#if !defined(MFL_CC) || !defined(MFL_KIND)
+#error "compile with -DMFL_CC=<channel chunk width> -DMFL_KIND=<1 forward | 2 backward | 3 fused step>"
 #endif
 
 using namespace mfl;
@@ -29,9 +30,10 @@ __device__ __forceinline__ const int *stage_table(const int *__restrict__ tab_g,
     }
 }
 
+#if MFL_KIND == 1
 // y[b][c][l] = x[b][c][l] * sum_t w[b][l][t] * S[b][c][l][t]
-// grid: (ceil(units / 256), channel chunks, B)
-template <int CC, int M, bool FROM_CD, bool TAB_LDS>
+// grid: (blocks_per_image, channel chunks, B)
+template <int CC, int M, bool FROM_CD, bool TAB_LDS, bool EXACT>
 __global__ void __launch_bounds__(kThreads)
 local_forward_kernel(Geom g, const float *__restrict__ xp, const F4 *__restrict__ ip4, const float *__restrict__ cd,
                      const int *__restrict__ tab_g, const float *__restrict__ pos_w, const float *__restrict__ col_w,
@@ -42,9 +44,8 @@ local_forward_kernel(Geom g, const float *__restrict__ xp, const F4 *__restrict_
 
     const int b = blockIdx.z, c0 = blockIdx.y * CC;
     const int nch = min(CC, g.C - c0);
-    const int uraw = blockIdx.x * kThreads + threadIdx.x;
     Columns<M> col;
-    make_columns<M>(col, g, min(uraw, g.units - 1), uraw < g.units);
+    make_columns<M>(col, g, blockIdx.x, threadIdx.x);
 
     const float *xp_b = xp + (size_t)b * g.C * g.plane;
     const F4 *ip_b = FROM_CD ? nullptr : ip4 + (size_t)b * g.plane;
@@ -58,9 +59,9 @@ local_forward_kernel(Geom g, const float *__restrict__ xp, const F4 *__restrict_
 
     NoSink sink;
     if constexpr (TAB_LDS)
-        window_sums<CC, M, FROM_CD>(acc, g, xp_b, ip_b, cd_b, lds_tab, *pos_w, *col_w, c0, nch, col, nullptr, sink);
+        window_sums<CC, M, FROM_CD, EXACT>(acc, g, xp_b, ip_b, cd_b, lds_tab, *pos_w, *col_w, c0, nch, col, nullptr, sink);
     else
-        window_sums<CC, M, FROM_CD>(acc, g, xp_b, ip_b, cd_b, tab, *pos_w, *col_w, c0, nch, col, nullptr, sink);
+        window_sums<CC, M, FROM_CD, EXACT>(acc, g, xp_b, ip_b, cd_b, tab, *pos_w, *col_w, c0, nch, col, nullptr, sink);
 
     const int ctr_off = g.p0 * g.Wp + g.p0;
     float *y_b = y + (size_t)b * g.C * g.L;
@@ -77,11 +78,14 @@ local_forward_kernel(Geom g, const float *__restrict__ xp, const F4 *__restrict_
     }
 }
 
+#endif  // MFL_KIND == 1
+
+#if MFL_KIND == 3
 // One fused mean-field update (all C <= CC channels of a pixel live in one thread):
 //   msg = Q_t * window_sum(Q_t);  msg = aw*msg + ab;  P = compat . msg;
 //   logQ = LogSoftmax(log_softmax(U) - P);  Q_{t+1} = exp(logQ) -> interior of qp_out
-// grid: (ceil(units / 256), 1, B).  LDS: [offset table][compat matrix].
-template <int CC, int M, bool TAB_LDS>
+// grid: (blocks_per_image, 1, B).  LDS: [offset table][compat matrix].
+template <int CC, int M, bool TAB_LDS, bool EXACT>
 __global__ void __launch_bounds__(kThreads)
 meanfield_step_kernel(Geom g, const float *__restrict__ qp_in, const F4 *__restrict__ ip4,
                       const int *__restrict__ tab_g, const float *__restrict__ pos_w, const float *__restrict__ col_w,
@@ -96,9 +100,8 @@ meanfield_step_kernel(Geom g, const float *__restrict__ qp_in, const F4 *__restr
     if constexpr (!TAB_LDS) __syncthreads();
 
     const int b = blockIdx.z, C = g.C;
-    const int uraw = blockIdx.x * kThreads + threadIdx.x;
     Columns<M> col;
-    make_columns<M>(col, g, min(uraw, g.units - 1), uraw < g.units);
+    make_columns<M>(col, g, blockIdx.x, threadIdx.x);
 
     const float *qp_b = qp_in + (size_t)b * C * g.plane;
     const F4 *ip_b = ip4 + (size_t)b * g.plane;
@@ -111,9 +114,9 @@ meanfield_step_kernel(Geom g, const float *__restrict__ qp_in, const F4 *__restr
 
     NoSink sink;
     if constexpr (TAB_LDS)
-        window_sums<CC, M, false>(acc, g, qp_b, ip_b, nullptr, lds_tab, *pos_w, *col_w, 0, C, col, nullptr, sink);
+        window_sums<CC, M, false, EXACT>(acc, g, qp_b, ip_b, nullptr, lds_tab, *pos_w, *col_w, 0, C, col, nullptr, sink);
     else
-        window_sums<CC, M, false>(acc, g, qp_b, ip_b, nullptr, tab, *pos_w, *col_w, 0, C, col, nullptr, sink);
+        window_sums<CC, M, false, EXACT>(acc, g, qp_b, ip_b, nullptr, tab, *pos_w, *col_w, 0, C, col, nullptr, sink);
 
     const int ctr_off = g.p0 * g.Wp + g.p0;
     const float *u_b = unary + (size_t)b * C * g.L;
@@ -169,6 +172,9 @@ meanfield_step_kernel(Geom g, const float *__restrict__ qp_in, const F4 *__restr
     }
 }
 
+#endif  // MFL_KIND == 3
+
+#if MFL_KIND == 2
 // Backward of local_forward_kernel.  Mirrors the forward loop: the same gather gives
 // S, from which  out (for dx = dy*out), u_t = sum_c D*S (for the two parameter
 // gradients and dcd) follow, and the scatter half of dx is added with float atomics
@@ -212,7 +218,7 @@ struct BackwardSink {
     }
 };
 
-template <int CC, int M, bool FROM_CD, bool TAB_LDS>
+template <int CC, int M, bool FROM_CD, bool TAB_LDS, bool EXACT>
 __global__ void __launch_bounds__(kThreads)
 local_backward_kernel(Geom g, const float *__restrict__ xp, const F4 *__restrict__ ip4, const float *__restrict__ cd,
                       const int *__restrict__ tab_g, const float *__restrict__ pos_w, const float *__restrict__ col_w,
@@ -225,9 +231,8 @@ local_backward_kernel(Geom g, const float *__restrict__ xp, const F4 *__restrict
 
     const int b = blockIdx.z, c0 = blockIdx.y * CC;
     const int nch = min(CC, g.C - c0);
-    const int uraw = blockIdx.x * kThreads + threadIdx.x;
     Columns<M> col;
-    make_columns<M>(col, g, min(uraw, g.units - 1), uraw < g.units);
+    make_columns<M>(col, g, blockIdx.x, threadIdx.x);
 
     const float *xp_b = xp + (size_t)b * g.C * g.plane;
     const F4 *ip_b = FROM_CD ? nullptr : ip4 + (size_t)b * g.plane;
@@ -265,9 +270,9 @@ local_backward_kernel(Geom g, const float *__restrict__ xp, const F4 *__restrict
     sink.dcd_atomic = gridDim.y > 1;
 
     if constexpr (TAB_LDS)
-        window_sums<CC, M, FROM_CD>(acc, g, xp_b, ip_b, cd_b, lds_tab, *pos_w, *col_w, c0, nch, col, D, sink);
+        window_sums<CC, M, FROM_CD, EXACT>(acc, g, xp_b, ip_b, cd_b, lds_tab, *pos_w, *col_w, c0, nch, col, D, sink);
     else
-        window_sums<CC, M, FROM_CD>(acc, g, xp_b, ip_b, cd_b, tab, *pos_w, *col_w, c0, nch, col, D, sink);
+        window_sums<CC, M, FROM_CD, EXACT>(acc, g, xp_b, ip_b, cd_b, tab, *pos_w, *col_w, c0, nch, col, D, sink);
 
     float *dxd_b = dxd + (size_t)b * g.C * g.L;
 #pragma unroll
@@ -297,42 +302,65 @@ local_backward_kernel(Geom g, const float *__restrict__ xp, const F4 *__restrict
     }
 }
 
+#endif  // MFL_KIND == 2
 
+
+#if MFL_KIND == 1
 template <int CC, int M, bool FROM_CD, bool TAB_LDS>
 int launch_fwd(const GatherArgs &a, float *y, hipStream_t st)
 {
     const Geom &g = a.g;
     if (g.M != M) return MFL_ERR_INVALID_ARGUMENT;
-    const dim3 grid((g.units + kThreads - 1) / kThreads, (g.C + CC - 1) / CC, g.B);
+    const dim3 grid(blocks_per_image(g), (g.C + CC - 1) / CC, g.B);
     const size_t lds = TAB_LDS ? (size_t)g.CK * 4 : 0;
-    hipLaunchKernelGGL((local_forward_kernel<CC, M, FROM_CD, TAB_LDS>), grid, dim3(kThreads), lds, st, g, a.xp, a.ip4,
-                       a.cd, a.tab, a.pos_w, a.col_w, y);
+    if (g.C % CC == 0)   // every chunk is full: no per-channel range checks in the kernel
+        hipLaunchKernelGGL((local_forward_kernel<CC, M, FROM_CD, TAB_LDS, true>), grid, dim3(kThreads), lds, st, g,
+                           a.xp, a.ip4, a.cd, a.tab, a.pos_w, a.col_w, y);
+    else
+        hipLaunchKernelGGL((local_forward_kernel<CC, M, FROM_CD, TAB_LDS, false>), grid, dim3(kThreads), lds, st, g,
+                           a.xp, a.ip4, a.cd, a.tab, a.pos_w, a.col_w, y);
     return (int)hipGetLastError();
 }
 
+#endif  // MFL_KIND == 1
+
+#if MFL_KIND == 2
 template <int CC, int M, bool FROM_CD, bool TAB_LDS>
 int launch_bwd(const GatherArgs &a, const BackwardArgs &b, hipStream_t st)
 {
     const Geom &g = a.g;
     if (g.M != M) return MFL_ERR_INVALID_ARGUMENT;
-    const dim3 grid((g.units + kThreads - 1) / kThreads, (g.C + CC - 1) / CC, g.B);
+    const dim3 grid(blocks_per_image(g), (g.C + CC - 1) / CC, g.B);
     const size_t lds = TAB_LDS ? (size_t)g.CK * 4 : 0;
-    hipLaunchKernelGGL((local_backward_kernel<CC, M, FROM_CD, TAB_LDS>), grid, dim3(kThreads), lds, st, g, a.xp, a.ip4,
-                       a.cd, a.tab, a.pos_w, a.col_w, b.dy, b.dxd, b.dxp, b.partials, b.dcd);
+    if (g.C % CC == 0)
+        hipLaunchKernelGGL((local_backward_kernel<CC, M, FROM_CD, TAB_LDS, true>), grid, dim3(kThreads), lds, st, g,
+                           a.xp, a.ip4, a.cd, a.tab, a.pos_w, a.col_w, b.dy, b.dxd, b.dxp, b.partials, b.dcd);
+    else
+        hipLaunchKernelGGL((local_backward_kernel<CC, M, FROM_CD, TAB_LDS, false>), grid, dim3(kThreads), lds, st, g,
+                           a.xp, a.ip4, a.cd, a.tab, a.pos_w, a.col_w, b.dy, b.dxd, b.dxp, b.partials, b.dcd);
     return (int)hipGetLastError();
 }
 
+#endif  // MFL_KIND == 2
+
+#if MFL_KIND == 3
 template <int CC, int M, bool TAB_LDS>
 int launch_step(const GatherArgs &a, const StepArgs &s, hipStream_t st)
 {
     const Geom &g = a.g;
     if (g.M != M || g.C > CC) return MFL_ERR_INVALID_ARGUMENT;
-    const dim3 grid((g.units + kThreads - 1) / kThreads, 1, g.B);
+    const dim3 grid(blocks_per_image(g), 1, g.B);
     const size_t lds = (TAB_LDS ? (size_t)((g.CK + 3) & ~3) * 4 : 0) + (size_t)g.C * g.C * 4;
-    hipLaunchKernelGGL((meanfield_step_kernel<CC, M, TAB_LDS>), grid, dim3(kThreads), lds, st, g, a.xp, a.ip4, a.tab,
-                       a.pos_w, a.col_w, s.unary, s.aw, s.ab, s.compat, s.logq, s.qp_out);
+    if (g.C == CC)
+        hipLaunchKernelGGL((meanfield_step_kernel<CC, M, TAB_LDS, true>), grid, dim3(kThreads), lds, st, g, a.xp,
+                           a.ip4, a.tab, a.pos_w, a.col_w, s.unary, s.aw, s.ab, s.compat, s.logq, s.qp_out);
+    else
+        hipLaunchKernelGGL((meanfield_step_kernel<CC, M, TAB_LDS, false>), grid, dim3(kThreads), lds, st, g, a.xp,
+                           a.ip4, a.tab, a.pos_w, a.col_w, s.unary, s.aw, s.ab, s.compat, s.logq, s.qp_out);
     return (int)hipGetLastError();
 }
+
+#endif  // MFL_KIND == 3
 
 // Pixels per thread the image-weight, LDS-table variants are built for at this width
 // (accumulator tile CC*M kept within the register budget).
@@ -345,6 +373,7 @@ namespace mfl {
 #define MFL_CAT2(a, b) a##b
 #define MFL_CAT(a, b) MFL_CAT2(a, b)
 
+#if MFL_KIND == 1
 int MFL_CAT(launch_local_forward_cc, MFL_CC)(const GatherArgs &a, float *y, hipStream_t st)
 {
     constexpr int CC = MFL_CC;
@@ -359,6 +388,9 @@ int MFL_CAT(launch_local_forward_cc, MFL_CC)(const GatherArgs &a, float *y, hipS
     return MFL_ERR_INVALID_ARGUMENT;
 }
 
+#endif  // MFL_KIND == 1
+
+#if MFL_KIND == 2
 int MFL_CAT(launch_local_backward_cc, MFL_CC)(const GatherArgs &a, const BackwardArgs &b, hipStream_t st)
 {
     constexpr int CC = MFL_CC;
@@ -372,6 +404,9 @@ int MFL_CAT(launch_local_backward_cc, MFL_CC)(const GatherArgs &a, const Backwar
     return MFL_ERR_INVALID_ARGUMENT;
 }
 
+#endif  // MFL_KIND == 2
+
+#if MFL_KIND == 3
 int MFL_CAT(launch_meanfield_step_cc, MFL_CC)(const GatherArgs &a, const StepArgs &s, hipStream_t st)
 {
     constexpr int CC = MFL_CC;
@@ -383,5 +418,7 @@ int MFL_CAT(launch_meanfield_step_cc, MFL_CC)(const GatherArgs &a, const StepArg
     }
     return MFL_ERR_INVALID_ARGUMENT;
 }
+
+#endif  // MFL_KIND == 3
 
 }  // namespace mfl

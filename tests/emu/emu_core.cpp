@@ -18,20 +18,20 @@ template <int CC, int M, bool FROM_CD>
 void run(const Geom &g, const float *xp, const F4 *ip4, const float *cd, const int *tab, float pw, float cw, float *y)
 {
     const int nchunks = (g.C + CC - 1) / CC;
-    const int nthreads = (g.units + 255) / 256 * 256;   // include the grid-tail duplicates
+    const int nthreads = blocks_per_image(g) * 256;     // include the inactive tail lanes
     const int ctr_off = g.p0 * g.Wp + g.p0;
     for (int b = 0; b < g.B; ++b)
         for (int chunk = 0; chunk < nchunks; ++chunk)
             for (int uraw = 0; uraw < nthreads; ++uraw) {
                 const int c0 = chunk * CC, nch = (g.C - c0 < CC) ? g.C - c0 : CC;
                 Columns<M> col;
-                make_columns<M>(col, g, uraw < g.units ? uraw : g.units - 1, uraw < g.units);
+                make_columns<M>(col, g, uraw / 256, uraw % 256);
                 const float *xp_b = xp + (size_t)b * g.C * g.plane;
                 float acc[CC][M];
                 for (int cc = 0; cc < CC; ++cc)
                     for (int n = 0; n < M; ++n) acc[cc][n] = 0.f;
                 NoSink sink;
-                window_sums<CC, M, FROM_CD>(acc, g, xp_b, FROM_CD ? nullptr : ip4 + (size_t)b * g.plane,
+                window_sums<CC, M, FROM_CD, false>(acc, g, xp_b, FROM_CD ? nullptr : ip4 + (size_t)b * g.plane,
                                             FROM_CD ? cd + (size_t)b * g.L * g.K : nullptr, tab, pw, cw, c0, nch, col,
                                             nullptr, sink);
                 for (int n = 0; n < M; ++n)
