@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmfl.so")
+# MFL_LIBRARY selects another build of the same ABI (kernel experiments); default: the in-tree library
+LIB_PATH = os.environ.get("MFL_LIBRARY") or os.path.join(_HERE, "libmfl.so")
 
 OP_LOCAL_FORWARD = 1
 OP_LOCAL_BACKWARD = 2

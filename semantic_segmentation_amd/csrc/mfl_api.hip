@@ -306,6 +306,14 @@ int launch_prepare(const Geom &g, const float *x, const float *img, float *xp, F
 }
 
 // ---- dispatch over the channel-chunk widths -----------------------------------
+#if defined(MFL_DEV_CC)
+// development build: only one channel-chunk width (and possibly one kernel kind) is linked
+#define MFL_CAT2(a, b) a##b
+#define MFL_CAT(a, b) MFL_CAT2(a, b)
+#define MFL_BY_CC(cc, fn, ...) \
+    if (cc == MFL_DEV_CC) return MFL_CAT(fn##_cc, MFL_DEV_CC)(__VA_ARGS__); \
+    return MFL_ERR_INVALID_ARGUMENT;
+#else
 #define MFL_BY_CC(cc, fn, ...)                    \
     switch (cc) {                                 \
     case 8: return fn##_cc8(__VA_ARGS__);         \
@@ -313,7 +321,12 @@ int launch_prepare(const Geom &g, const float *x, const float *img, float *xp, F
     case 21: return fn##_cc21(__VA_ARGS__);       \
     default: return fn##_cc32(__VA_ARGS__);       \
     }
+#endif
 
+#if defined(MFL_DEV_CC) && defined(MFL_DEV_STEP_ONLY)
+int dispatch_local_forward(int, const GatherArgs &, float *, hipStream_t) { return MFL_ERR_INVALID_ARGUMENT; }
+int dispatch_local_backward(int, const GatherArgs &, const BackwardArgs &, hipStream_t) { return MFL_ERR_INVALID_ARGUMENT; }
+#else
 int dispatch_local_forward(int cc, const GatherArgs &a, float *y, hipStream_t st)
 {
     MFL_BY_CC(cc, launch_local_forward, a, y, st)
@@ -322,6 +335,7 @@ int dispatch_local_backward(int cc, const GatherArgs &a, const BackwardArgs &b, 
 {
     MFL_BY_CC(cc, launch_local_backward, a, b, st)
 }
+#endif
 int dispatch_meanfield_step(int cc, const GatherArgs &a, const StepArgs &s, hipStream_t st)
 {
     MFL_BY_CC(cc, launch_meanfield_step, a, s, st)
@@ -336,6 +350,9 @@ int setup(Geom &g, int &cc, bool &tab_lds, int B, int C, int H, int W, int k, bo
     if (rc) return rc == -3 ? MFL_ERR_TOO_LARGE : MFL_ERR_INVALID_ARGUMENT;
     cc = pick_cc(C);
     tab_lds = (size_t)g1.CK * 4 + 16 + extra_lds <= (size_t)kMaxLdsBytes;
+#ifdef MFL_DEV_MAX_M
+    max_m = MFL_DEV_MAX_M;   // kernel experiments: force the pixels-per-thread variant
+#endif
     int m = (from_cd || !tab_lds) ? 1 : pick_m(g1, cc, max_m);
     rc = make_geom(g, B, C, H, W, k, m);
     if (rc) return rc == -3 ? MFL_ERR_TOO_LARGE : MFL_ERR_INVALID_ARGUMENT;

@@ -147,7 +147,10 @@ MFL_D bool wave_any(bool pred)
 // consecutive t_0 from consecutive taps of the same padded row, so one wave-wide gather
 // reads a few contiguous row pieces of about M*kWaveTiles + k floats instead of 64/k short
 // ones.  The 4 waves of a 256-thread block take consecutive t_0 groups of the same tiles.
-constexpr int kWaveTiles = 4;
+#ifndef MFL_WAVE_TILES
+#define MFL_WAVE_TILES 4
+#endif
+constexpr int kWaveTiles = MFL_WAVE_TILES;
 constexpr int kWaveR = 64 / kWaveTiles;
 constexpr int kBlockWaves = 4;
 constexpr int kBlockR = kWaveR * kBlockWaves;
@@ -264,9 +267,15 @@ MFL_D void window_sums(float (&acc)[CC][M], const Geom &g, const float *__restri
                         int ai = lin + tab[r];
                         if (cb + i == 0) a_first = ai;
                         if constexpr (!EXACT) ai = (cb + i < nch) ? ai : a_first;   // channels past the chunk: a valid dummy
+#ifdef MFL_DBG_SMALL_REGION
+                        ai &= 0x3ff;   // timing experiment only: every gather hits the same 4 KB
+#endif
                         a[i] = ai;
                         xc[i] = x;
                         if constexpr (M > 1) cross |= (x + M > W);
+#ifdef MFL_DBG_TRIVIAL_STEP
+                        lin += dK_lin;   // timing experiment only: no carries, wrong results
+#else
                         r += g.rhoK;
                         const int carry = r >= g.CK;
                         r -= carry ? g.CK : 0;
@@ -274,12 +283,22 @@ MFL_D void window_sums(float (&acc)[CC][M], const Geom &g, const float *__restri
                         const int wrap = x >= W;
                         x -= wrap ? W : 0;
                         lin += dK_lin + carry + (wrap ? gap : 0);
+#endif
                     }
                 }
                 // phase B: the batch's loads.  A run that crosses the end of an image row continues
                 // `gap` floats later; that is rare, so ONE wave-uniform branch per batch selects between
                 // the all-wide form and a form in which the crossing lanes load their floats one by one.
                 float v[CB][M];
+#ifdef MFL_DBG_NO_LOADS
+                if (true) {   // timing experiment only: no gather loads, wrong results
+#pragma unroll
+                    for (int i = 0; i < CB; ++i)
+                        if (cb + i < CC)
+#pragma unroll
+                            for (int n = 0; n < M; ++n) v[i][n] = __int_as_float(a[i] + n);
+                } else
+#endif
                 if (M == 1 || !wave_any(cross)) {
 #pragma unroll
                     for (int i = 0; i < CB; ++i)

@@ -354,9 +354,11 @@ int launch_step(const GatherArgs &a, const StepArgs &s, hipStream_t st)
     if (g.C == CC)
         hipLaunchKernelGGL((meanfield_step_kernel<CC, M, TAB_LDS, true>), grid, dim3(kThreads), lds, st, g, a.xp,
                            a.ip4, a.tab, a.pos_w, a.col_w, s.unary, s.aw, s.ab, s.compat, s.logq, s.qp_out);
+#ifndef MFL_DEV_FAST
     else
         hipLaunchKernelGGL((meanfield_step_kernel<CC, M, TAB_LDS, false>), grid, dim3(kThreads), lds, st, g, a.xp,
                            a.ip4, a.tab, a.pos_w, a.col_w, s.unary, s.aw, s.ab, s.compat, s.logq, s.qp_out);
+#endif
     return (int)hipGetLastError();
 }
 
@@ -410,6 +412,10 @@ int MFL_CAT(launch_local_backward_cc, MFL_CC)(const GatherArgs &a, const Backwar
 int MFL_CAT(launch_meanfield_step_cc, MFL_CC)(const GatherArgs &a, const StepArgs &s, hipStream_t st)
 {
     constexpr int CC = MFL_CC;
+#ifdef MFL_DEV_FAST   // kernel experiments: only the M = MFL_DEV_FAST, LDS-table, exact-width variant is built
+    if (a.tab_lds && a.g.M == MFL_DEV_FAST && a.g.C == CC) return launch_step<CC, MFL_DEV_FAST, true>(a, s, st);
+    return MFL_ERR_INVALID_ARGUMENT;
+#else
     if (!a.tab_lds) return launch_step<CC, 1, false>(a, s, st);
     switch (a.g.M) {
     case 1: return launch_step<CC, 1, true>(a, s, st);
@@ -417,6 +423,7 @@ int MFL_CAT(launch_meanfield_step_cc, MFL_CC)(const GatherArgs &a, const StepArg
     case 4: if constexpr (kMaxM >= 4) return launch_step<CC, 4, true>(a, s, st);
     }
     return MFL_ERR_INVALID_ARGUMENT;
+#endif
 }
 
 #endif  // MFL_KIND == 3
