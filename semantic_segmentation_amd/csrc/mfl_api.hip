@@ -16,6 +16,7 @@
 
 #include "../../include/mfl.h"
 #include "mfl_gather.h"
+#include "mfl_diag_api.h"
 
 using namespace mfl;
 
@@ -359,6 +360,75 @@ int setup(Geom &g, int &cc, bool &tab_lds, int B, int C, int H, int W, int k, bo
     return MFL_OK;
 }
 
+
+// ---- diagonal gather path (mfl_diag.hip): images at least 64 + k wide, C <= 33, odd k <= 11 ----
+constexpr int kDiagWeightLds = 120 * 1024;   // LDS budget of the double-buffered tap-weight table
+
+struct DiagWorkspace {
+    size_t xp, xp2, ip4, table, groups, total;
+};
+
+size_t diag_padded_floats(const DiagGeom &g) { return (size_t)g.FS + (size_t)g.B * g.C * g.plane + 3 * (size_t)g.Wp + 64; }
+
+DiagWorkspace diag_carve(int op, const DiagGeom &g)
+{
+    DiagWorkspace w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    w.xp = take(diag_padded_floats(g) * 4);
+    if (op == MFL_OP_MEANFIELD_FORWARD) w.xp2 = take(diag_padded_floats(g) * 4);
+    w.ip4 = take(((size_t)g.B * g.plane + 64) * sizeof(F4));
+    w.table = take(diag_table_dwords(g) * 4);
+    w.groups = take((size_t)g.k * g.k * 4);
+    w.total = off;
+    return w;
+}
+
+bool diag_eligible(int op, int B, int C, int H, int W, int k, DiagGeom &g)
+{
+    if (op != MFL_OP_LOCAL_FORWARD && op != MFL_OP_MEANFIELD_FORWARD) return false;
+    if (op == MFL_OP_MEANFIELD_FORWARD && C > 32) return false;
+    return make_diag_geom(g, B, C, H, W, k, kDiagWeightLds) == 0;
+}
+
+int dispatch_diag(const DiagArgs &a, int mode, hipStream_t st)
+{
+#define MFL_DIAG_CASE(CHV, KSV) \
+    if (a.g.CH == CHV && a.g.k == KSV) return launch_diag_ch##CHV##_k##KSV(a, mode, st);
+#define MFL_DIAG_CASES(KSV) MFL_DIAG_CASE(8, KSV) MFL_DIAG_CASE(10, KSV) MFL_DIAG_CASE(11, KSV)
+    MFL_DIAG_CASES(3) MFL_DIAG_CASES(5) MFL_DIAG_CASES(7) MFL_DIAG_CASES(9) MFL_DIAG_CASES(11)
+#undef MFL_DIAG_CASES
+#undef MFL_DIAG_CASE
+    return MFL_ERR_INVALID_ARGUMENT;
+}
+
+// Pads x (planes) and img, builds the address table and the weight-group list.  x_floats: the padded
+// buffer (front slack included) that receives x.
+int diag_prepare(const DiagGeom &g, const float *x, const float *img, float *x_floats, F4 *ip4, uint32_t *table,
+                 uint32_t *groups_dev, hipStream_t st)
+{
+    const size_t n = (size_t)g.B * g.C * g.plane;
+    MFL_CHECK_HIP(hipMemsetAsync(x_floats, 0, (size_t)g.FS * 4, st));
+    hipLaunchKernelGGL(pad_planes_kernel, dim3(grid_for(n)), dim3(kThreads), 0, st, x, x_floats + g.FS, g.B * g.C, g.H,
+                       g.W, g.Hp, g.Wp, g.p0);
+    MFL_CHECK_HIP(hipMemsetAsync(x_floats + g.FS + n, 0, (3 * (size_t)g.Wp + 64) * 4, st));
+    const size_t ni = (size_t)g.B * g.plane;
+    hipLaunchKernelGGL(pad_image4_kernel, dim3(grid_for(ni)), dim3(kThreads), 0, st, img, ip4, g.B, g.H, g.W, g.Hp,
+                       g.Wp, g.p0);
+    MFL_CHECK_HIP(hipMemsetAsync(ip4 + ni, 0, 64 * sizeof(F4), st));
+    return launch_diag_table(g, table, groups_dev, st);
+}
+
+void diag_lds(const DiagGeom &g, DiagArgs &a)
+{
+    const size_t wbytes = 2 * (size_t)g.TB * g.NBR * g.RUNP * 4;
+    const size_t lds = wbytes > 96 * 1024 ? wbytes : 96 * 1024;
+    int rows = (int)(lds / ((size_t)g.C * g.RUNP * 4));
+    if (rows > g.NBR) rows = g.NBR;
+    a.lds_bytes = lds;
+    a.epi_rows = rows;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ C ABI
@@ -382,6 +452,8 @@ size_t mfl_workspace_bytes(int op, int B, int C, int H, int W, int k, int iters)
 {
     (void)iters;
     if (op != MFL_OP_LOCAL_FORWARD && op != MFL_OP_LOCAL_BACKWARD && op != MFL_OP_MEANFIELD_FORWARD) return 0;
+    DiagGeom dg;
+    if (diag_eligible(op, B, C, H, W, k, dg)) return diag_carve(op, dg).total;
     Geom g;
     if (make_geom(g, B, C, H, W, k, 1)) return 0;
     return carve(op, g, pick_cc(C)).total;
@@ -404,6 +476,27 @@ int mfl_local_forward(const float *x, const float *img, const float *cd, const f
     int rc = check_common(x, y, B, C, H, W, k);
     if (rc) return rc;
     if (!pos_w || !col_w || (img == nullptr) == (cd == nullptr)) return MFL_ERR_INVALID_ARGUMENT;
+    DiagGeom dg;
+    if (img && diag_eligible(MFL_OP_LOCAL_FORWARD, B, C, H, W, k, dg)) {
+        const DiagWorkspace ws = diag_carve(MFL_OP_LOCAL_FORWARD, dg);
+        if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
+        char *base = (char *)workspace;
+        hipStream_t st = (hipStream_t)stream;
+        rc = diag_prepare(dg, x, img, (float *)(base + ws.xp), (F4 *)(base + ws.ip4), (uint32_t *)(base + ws.table),
+                          (uint32_t *)(base + ws.groups), st);
+        if (rc) return rc;
+        DiagArgs da{};
+        da.g = dg;
+        diag_lds(dg, da);
+        da.xp = (const float *)(base + ws.xp);
+        da.ip4 = (const F4 *)(base + ws.ip4);
+        da.table = (const uint32_t *)(base + ws.table);
+        da.groups = (const uint32_t *)(base + ws.groups);
+        da.pos_w = pos_w;
+        da.col_w = col_w;
+        da.y = y;
+        return dispatch_diag(da, 1, st);
+    }
     Geom g;
     int cc;
     bool tab_lds;
@@ -483,6 +576,39 @@ int mfl_meanfield_forward(const float *unary, const float *img, const float *pos
     if (rc) return rc;
     if (!logq || !pos_w || !col_w || iters <= 0 || (affine_w == nullptr) != (affine_b == nullptr))
         return MFL_ERR_INVALID_ARGUMENT;
+    DiagGeom dg;
+    if (diag_eligible(MFL_OP_MEANFIELD_FORWARD, B, C, H, W, k, dg)) {
+        const DiagWorkspace ws = diag_carve(MFL_OP_MEANFIELD_FORWARD, dg);
+        if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
+        char *base = (char *)workspace;
+        hipStream_t st = (hipStream_t)stream;
+        float *qa = (float *)(base + ws.xp), *qb = (float *)(base + ws.xp2);
+        rc = diag_prepare(dg, unary, img, qa, (F4 *)(base + ws.ip4), (uint32_t *)(base + ws.table),
+                          (uint32_t *)(base + ws.groups), st);
+        if (rc) return rc;
+        MFL_CHECK_HIP(hipMemsetAsync(qb, 0, diag_padded_floats(dg) * 4, st));   // borders of the other buffer
+        DiagArgs da{};
+        da.g = dg;
+        diag_lds(dg, da);
+        da.ip4 = (const F4 *)(base + ws.ip4);
+        da.table = (const uint32_t *)(base + ws.table);
+        da.groups = (const uint32_t *)(base + ws.groups);
+        da.pos_w = pos_w;
+        da.col_w = col_w;
+        da.unary = unary;
+        da.aw = affine_w;
+        da.ab = affine_b;
+        da.compat = compat;
+        for (int it = 0; it < iters; ++it) {
+            da.xp = qa;
+            da.qp_out = qb;
+            da.logq = (it == iters - 1) ? logq : nullptr;
+            rc = dispatch_diag(da, 0, st);
+            if (rc) return rc;
+            float *t = qa; qa = qb; qb = t;
+        }
+        return MFL_OK;
+    }
     const bool fused = C <= 32;
     Geom g;
     int cc;

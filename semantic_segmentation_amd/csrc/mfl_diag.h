@@ -1,0 +1,215 @@
+// Geometry, ownership map and address tables of the "diagonal" gather kernels
+// (mfl_diag.hip): the fast path of the local-window message passing for images at
+// least 64 + k pixels wide.  Plain C++ shared by the device code and by the host
+// emulation in the CPU test-suite.
+//
+// Arithmetic restated (not code) from Conv2dLocal.forward, LocalConvolution.py:59-90.
+//
+// ---- the index map, seen along its diagonals ---------------------------------
+// With K = k*k, L = H*W, CK = C*K, output (c, l), tap t reads V[g], g = (c*K + t)*L + l,
+// where V[l'*CK + c'*K + ky'*k + kx'] = pad(x)[c'][y' + ky'][x' + kx']  (mfl_core.h).
+// Write an output pixel as l = a + b*CK (a < CK) and g = G + n + b*CK with
+// G = (c*K + t)*L + a0 = l0'*CK + r0.  Adding CK to g moves to the next source pixel
+// (address + 1), adding 1 moves to the next kx' (address + 1), so the pixels
+//     (a0 + n, b - n),  n = 0 .. k-1
+// all read the SAME element of pad(x) as long as r0 % k + n < k; the others read one
+// common element of the next (c', ky') line.  A thread therefore owns such a diagonal
+// of k output pixels: per (channel, tap) it needs two loaded values (A, B) for k FMAs,
+// and the 64 lanes of a wave, which own consecutive b, load 64 consecutive floats.
+// s = r0 % k = (t*L) % k depends on the tap column kx only, so which pixels use A or B
+// is known per tap column and the kernels are specialised on it.
+//
+// The sharing breaks where the run of source pixels meets the start of an image row
+// (the zero padding of pad(x) separates rows by k-1 floats): such (channel, tap) steps
+// are flagged in the table and take a per-lane corrected path.
+//
+// ---- who computes what ---------------------------------------------------------
+// group      gamma = a0 / k           (C*k groups)
+// b-block    beta: lanes own b = 64*beta + lane - n
+// channels are split over NCS waves of CH channels each; a workgroup is NGW consecutive
+// groups x NCS channel splits and shares one table of tap weights in LDS.
+#ifndef MFL_DIAG_H
+#define MFL_DIAG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "mfl_core.h"
+
+namespace mfl {
+
+struct DiagGeom {
+    int B, C, H, W, k, K, p0;
+    int L, CK;
+    int Hp, Wp, plane, gap;   // zero-padded plane; gap = Wp - W = k - 1
+    int NB;                   // number of b values: ceil(L / CK)
+    int NG;                   // groups: C*k
+    int NBB;                  // b-blocks of 64 lanes
+    int NGW, NCS, CH;         // workgroup = NGW groups x NCS channel splits; CH channels per wave
+    int NGB;                  // group blocks: ceil(NG / NGW)
+    int RUN, RUNP;            // pixels of a workgroup along a (NGW*k) and the odd LDS pitch
+    int NBR;                  // b values a workgroup touches: 64 + k - 1
+    int Lk;                   // L % k
+    int FS;                   // floats of zeroed slack in front of the padded planes
+    int RECW;                 // dwords per table record
+    int TB;                   // taps per weight group
+    int ngroups;              // weight groups per iteration
+};
+
+// Floats of zeroed slack in front of (FS) and behind the padded planes of a batch.
+MFL_HD int diag_front_slack(int k) { return ((2 * k + 2 + 15) / 16) * 16; }
+
+inline bool diag_supported(int C, int H, int W, int k)
+{
+    if (!(k == 3 || k == 5 || k == 7 || k == 9 || k == 11)) return false;
+    if (C > 33 || W < 64 + k || W >= 16384) return false;
+    const long long CK = (long long)C * k * k, L = (long long)H * W;
+    if (L < 4 * CK) return false;   // too few source pixels per row of the scrambled matrix to fill a wave
+    return true;
+}
+
+// Channel split: CH channels per wave, NCS waves per group.
+inline void diag_split(int C, int &CH, int &NCS, int &NGW)
+{
+    if (C <= 8) { NCS = 1; NGW = 8; CH = 8; return; }
+    NCS = C <= 22 ? 2 : 3;
+    NGW = NCS == 2 ? 4 : 2;
+    const int need = (C + NCS - 1) / NCS;
+    CH = need <= 8 ? 8 : need <= 10 ? 10 : 11;
+}
+
+MFL_HD int diag_recw(int CH) { return ((2 * CH + 1 + (CH + 1) / 2 + 3) / 4) * 4; }
+
+// Returns 0 on success, -1 invalid, -3 too large for 32-bit indexing.
+inline int make_diag_geom(DiagGeom &g, int B, int C, int H, int W, int k, int lds_budget_bytes)
+{
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0) return -1;
+    if (!diag_supported(C, H, W, k)) return -1;
+    const long long K = (long long)k * k, L = (long long)H * W, CK = (long long)C * K;
+    const long long Hp = (long long)H + k - 1, Wp = (long long)W + k - 1, plane = Hp * Wp;
+    if (L >= (1LL << 30) || (C * plane + 4 * Wp + 256) * 4 >= (1LL << 31)) return -3;
+    g.B = B; g.C = C; g.H = H; g.W = W; g.k = k; g.K = (int)K; g.p0 = k / 2;
+    g.L = (int)L; g.CK = (int)CK; g.Hp = (int)Hp; g.Wp = (int)Wp; g.plane = (int)plane; g.gap = k - 1;
+    g.NB = (int)((L + CK - 1) / CK);
+    g.NG = C * k;
+    g.NBB = (g.NB + k - 1 + 63) / 64;
+    diag_split(C, g.CH, g.NCS, g.NGW);
+    g.NGB = (g.NG + g.NGW - 1) / g.NGW;
+    g.RUN = g.NGW * k;
+    g.RUNP = g.RUN | 1;
+    g.NBR = 64 + k - 1;
+    g.Lk = (int)(L % k);
+    g.FS = diag_front_slack(k);
+    g.RECW = diag_recw(g.CH);
+    int tb = k;
+    while (tb > 1 && 2LL * tb * g.NBR * g.RUNP * 4 > lds_budget_bytes) --tb;
+    g.TB = tb;
+    const int chunks = (k + tb - 1) / tb;
+    g.ngroups = k * chunks;
+    const long long recs = (long long)g.NBB * g.NG * K * g.NCS;
+    if (recs * g.RECW >= (1LL << 31)) return -3;
+    return 0;
+}
+
+MFL_HD size_t diag_table_dwords(const DiagGeom &g)
+{
+    return (size_t)g.NBB * g.NG * g.K * g.NCS * g.RECW;
+}
+
+MFL_HD size_t diag_record_index(const DiagGeom &g, int beta, int gamma, int t, int ci)
+{
+    return ((((size_t)beta * g.NG + gamma) * g.K + t) * g.NCS + ci) * g.RECW;
+}
+
+// One (b-block, group, tap, channel) step of the gather:
+//   offA / offB  float index, relative to FS floats before the image's padded planes, of the
+//                element lane 0 shares among its pixels with s + n < k (A) / s + n >= k (B);
+//   xA / xB      image column of lane 0's source pixel for A / B;
+//   flagged      the 64-lane run meets an image-row start: the per-lane corrected path is needed.
+struct DiagStep {
+    int offA, offB, xA, xB;
+    bool flagged;
+};
+
+MFL_HD DiagStep diag_step(const DiagGeom &g, int beta, int gamma, int t, int c)
+{
+    const long long G = ((long long)c * g.K + t) * g.L + (long long)gamma * g.k;
+    const long long lp0 = G / g.CK;
+    const int r0 = (int)(G - lp0 * g.CK);
+    const int rho = r0 / g.k, s = r0 - rho * g.k;
+    DiagStep st;
+    // A: line rho of source pixel lp0 + 64*beta
+    const long long uA = lp0 + 64LL * beta;
+    const int yA = (int)(uA / g.W);
+    st.xA = (int)(uA - (long long)yA * g.W);
+    const int cA = rho / g.k, kyA = rho - cA * g.k;
+    st.offA = g.FS + cA * g.plane + (yA + kyA) * g.Wp + st.xA + s;
+    // B: the next line, possibly of the next source pixel
+    long long uB = uA;
+    int rhoB = rho + 1;
+    if (rhoB == g.C * g.k) { rhoB = 0; uB = uA + 1; }
+    const int yB = (int)(uB / g.W);
+    st.xB = (int)(uB - (long long)yB * g.W);
+    const int cB = rhoB / g.k, kyB = rhoB - cB * g.k;
+    st.offB = g.FS + cB * g.plane + (yB + kyB) * g.Wp + st.xB + s - g.k;
+    const bool okA = st.xA >= g.k - 1 && st.xA + 63 <= g.W - 1;
+    const bool okB = st.xB >= g.k - 1 && st.xB + 63 <= g.W - 1;
+    st.flagged = !(okA && okB);
+    return st;
+}
+
+// Float index (same base as offA / offB) that lane `lane`, pixel n reads in a step whose side
+// (A or B) has offset `off` and lane-0 column `x0`.  The unflagged case reduces to off + lane.
+MFL_HD int diag_lane_index(const DiagGeom &g, int off, int x0, int lane, int n)
+{
+    int pos = x0 + lane;
+    const bool wrapped = pos >= g.W;
+    if (wrapped) pos -= g.W;
+    return off + lane + (wrapped ? g.gap : 0) - (pos < n ? g.gap : 0);
+}
+
+// Alignment of tap column kx: pixels n < k - s read A, the others B.
+MFL_HD int diag_align(const DiagGeom &g, int kx) { return (int)(((long long)kx * g.Lk) % g.k); }
+
+// Weight groups of one iteration: tap columns ordered by alignment class, each split into chunks of
+// at most TB taps.  Packed as s | kx << 8 | ky0 << 16 | nky << 24.
+MFL_HD int diag_groups(const DiagGeom &g, uint32_t *out)
+{
+    int n = 0;
+    for (int s = 0; s < g.k; ++s)
+        for (int kx = 0; kx < g.k; ++kx) {
+            if (diag_align(g, kx) != s) continue;
+            for (int ky0 = 0; ky0 < g.k; ky0 += g.TB) {
+                const int nky = (g.k - ky0 < g.TB) ? g.k - ky0 : g.TB;
+                out[n++] = (uint32_t)s | ((uint32_t)kx << 8) | ((uint32_t)ky0 << 16) | ((uint32_t)nky << 24);
+            }
+        }
+    return n;
+}
+
+// Fill one table record (all CH steps of one (beta, gamma, t, channel split)).
+//   [0, CH)        byte offsets of A        (channels past C repeat the first channel of the split)
+//   [CH, 2CH)      byte offsets of B
+//   [2CH]          bit i set: step i is flagged
+//   [2CH+1, ...)   16-bit pairs: xA | (xB != xA) << 15
+MFL_HD void diag_fill_record(const DiagGeom &g, int beta, int gamma, int t, int ci, uint32_t *rec)
+{
+    uint32_t flags = 0;
+    for (int i = 0; i < g.RECW; ++i) rec[i] = 0;
+    for (int i = 0; i < g.CH; ++i) {
+        int c = ci * g.CH + i;
+        const bool dummy = c >= g.C;
+        if (dummy) c = ci * g.CH < g.C ? ci * g.CH : 0;
+        const DiagStep st = diag_step(g, beta, gamma, t, c);
+        rec[i] = (uint32_t)st.offA * 4u;
+        rec[g.CH + i] = (uint32_t)st.offB * 4u;
+        if (st.flagged && !dummy) flags |= 1u << i;
+        const uint32_t x16 = (uint32_t)st.xA | ((st.xB != st.xA) ? 0x8000u : 0u);
+        rec[2 * g.CH + 1 + i / 2] |= x16 << (16 * (i & 1));
+    }
+    rec[2 * g.CH] = flags;
+}
+
+}  // namespace mfl
+
+#endif  // MFL_DIAG_H

@@ -1,0 +1,92 @@
+// Host emulation of the diagonal gather (semantic_segmentation_amd/csrc/mfl_diag.h): the address
+// table is built with the same functions the device uses and every (workgroup, wave, lane, pixel)
+// of the device kernel is replayed as loop iterations on the CPU, reading the padded planes only
+// through table offsets and the per-lane index rule.  It checks ownership (every pixel computed
+// exactly once), the A/B split per tap column, flagged steps and tails without a GPU.
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../semantic_segmentation_amd/csrc/mfl_diag.h"
+
+using namespace mfl;
+
+// y = x * window sums (Conv2dLocal.forward with the colour distance of img).  count[b][l] receives
+// how many times each output pixel was produced (must be exactly 1).  Returns 0 on success.
+extern "C" int emu_diag_local_forward(const float *x, const float *img, float pw, float cw, float *y, int *count, int B,
+                                      int C, int H, int W, int k)
+{
+    DiagGeom g;
+    int rc = make_diag_geom(g, B, C, H, W, k, 96 * 1024);
+    if (rc) return rc;
+    const size_t per_image = (size_t)C * g.plane;
+    const size_t npad = (size_t)g.FS + B * per_image + 3 * g.Wp + 64;
+    std::vector<float> buf(npad, 0.f);
+    float *xp = buf.data() + g.FS;
+    for (int bc = 0; bc < B * C; ++bc)
+        for (int yy = 0; yy < H; ++yy)
+            memcpy(&xp[((size_t)bc * g.Hp + yy + g.p0) * g.Wp + g.p0], x + ((size_t)bc * H + yy) * W, sizeof(float) * W);
+    std::vector<uint32_t> table(diag_table_dwords(g));
+    for (int beta = 0; beta < g.NBB; ++beta)
+        for (int gamma = 0; gamma < g.NG; ++gamma)
+            for (int t = 0; t < g.K; ++t)
+                for (int ci = 0; ci < g.NCS; ++ci)
+                    diag_fill_record(g, beta, gamma, t, ci, &table[diag_record_index(g, beta, gamma, t, ci)]);
+    std::vector<uint32_t> groups(g.k * g.k);
+    const int ngroups = diag_groups(g, groups.data());
+    if (ngroups != g.ngroups) return -10;
+
+    memset(y, 0, sizeof(float) * (size_t)B * C * g.L);
+    memset(count, 0, sizeof(int) * (size_t)B * g.L);
+    const size_t Lz = (size_t)g.L;
+    for (int b = 0; b < B; ++b) {
+        const float *base = buf.data() + (size_t)b * per_image;   // FS floats before image b's planes
+        const float *im = img + (size_t)b * 3 * Lz;
+        for (int beta = 0; beta < g.NBB; ++beta)
+            for (int gamma = 0; gamma < g.NG; ++gamma)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int n = 0; n < g.k; ++n) {
+                        const long long a = (long long)gamma * g.k + n, bb = 64LL * beta + lane - n;
+                        const long long l = a + bb * g.CK;
+                        if (bb < 0 || l >= g.L) continue;
+                        const int py = (int)(l / W), px = (int)(l % W);
+                        count[(size_t)b * Lz + l] += 1;
+                        for (int ci = 0; ci < g.NCS; ++ci)
+                            for (int i = 0; i < g.CH; ++i) {
+                                const int c = ci * g.CH + i;
+                                if (c >= C) continue;
+                                float acc = 0.f;
+                                for (int gi = 0; gi < ngroups; ++gi) {
+                                    const int s = groups[gi] & 255, kx = (groups[gi] >> 8) & 255;
+                                    const int ky0 = (groups[gi] >> 16) & 255, nky = groups[gi] >> 24;
+                                    for (int ky = ky0; ky < ky0 + nky; ++ky) {
+                                        const int t = ky * k + kx;
+                                        const uint32_t *rec = &table[diag_record_index(g, beta, gamma, t, ci)];
+                                        const bool flagged = (rec[2 * g.CH] >> i) & 1;
+                                        const uint32_t x16 = (rec[2 * g.CH + 1 + i / 2] >> (16 * (i & 1))) & 0xffff;
+                                        const int xA = x16 & 0x7fff;
+                                        int xB = xA;
+                                        if (x16 & 0x8000) xB = (xA + 1 == W) ? 0 : xA + 1;
+                                        const bool useA = s + n < k;
+                                        const int off = (int)(rec[useA ? i : g.CH + i] / 4);
+                                        const int idx = flagged ? diag_lane_index(g, off, useA ? xA : xB, lane, n) : off + lane;
+                                        // tap weight
+                                        const int ny = py + ky - g.p0, nx = px + kx - g.p0;
+                                        const bool in = ny >= 0 && ny < H && nx >= 0 && nx < W;
+                                        float cd = 0.f;
+                                        for (int ch = 0; ch < 3; ++ch) {
+                                            const float d = im[ch * Lz + l] - (in ? im[ch * Lz + (size_t)ny * W + nx] : 0.f);
+                                            cd += d * d;
+                                        }
+                                        const int dy = ky - g.p0, dx = kx - g.p0;
+                                        const float wgt = (float)(dy * dy + dx * dx) * pw + cd * cw;
+                                        acc += wgt * base[idx];
+                                    }
+                                }
+                                y[((size_t)b * C + c) * Lz + l] = acc * x[((size_t)b * C + c) * Lz + l];
+                            }
+                    }
+    }
+    return 0;
+}

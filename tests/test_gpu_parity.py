@@ -102,7 +102,15 @@ SHAPES = [  # B, C, H, W, k
     (1, 7, 9, 300, 5),         # wide and short
     (1, 21, 64, 64, 50),       # the model's own configuration (offset table in global memory)
     (1, 4, 31, 29, 1),         # 1x1 window
+    # wide enough for the diagonal gather kernels (W >= 64 + k, H*W >= 4*C*k*k)
+    (2, 21, 96, 112, 7),       # two channel splits of 11
+    (1, 19, 96, 128, 11),      # two channel splits of 10
+    (1, 23, 70, 90, 5),        # three channel splits
+    (2, 5, 40, 80, 5),
+    (1, 9, 50, 75, 3),
+    (1, 32, 90, 100, 3),
 ]
+DIAG_SHAPES = SHAPES[10:]
 
 
 def make_inputs(shape, seed=0):
@@ -151,7 +159,7 @@ def test_tensor_mode_equals_image_mode(shape, S):
     assert abs(got - float(dpb[1])) <= 1e-4 * abs(float(dpb[1])) + 1e-5
 
 
-@pytest.mark.parametrize("shape", [SHAPES[0], SHAPES[1], SHAPES[2], SHAPES[3], SHAPES[5]])
+@pytest.mark.parametrize("shape", [SHAPES[0], SHAPES[1], SHAPES[2], SHAPES[3], SHAPES[5]] + DIAG_SHAPES)
 @pytest.mark.parametrize("mode", ["plain", "compat", "affine+compat"])
 def test_meanfield_vs_oracle(shape, mode, S, oracle):
     B, C, H, W, k = shape
