@@ -361,12 +361,58 @@ int setup(Geom &g, int &cc, bool &tab_lds, int B, int C, int H, int W, int k, bo
 }
 
 
+#ifdef MFL_STAMPS
+unsigned long long *g_stamps = nullptr;   // diagnostic builds only: device buffer for in-kernel cycle stamps
+#define MFL_SET_DBG(da) (da).dbg = g_stamps
+#else
+#define MFL_SET_DBG(da) (da).dbg = nullptr
+#endif
+
 // ---- diagonal gather path (mfl_diag.hip): images at least 64 + k wide, C <= 33, odd k <= 11 ----
 constexpr int kDiagWeightLds = 120 * 1024;   // LDS budget of the double-buffered tap-weight table
 
+// Address table and weight-group list of the diagonal kernels, built on the device.
+__global__ void diag_table_kernel(DiagGeom g, uint32_t *__restrict__ table)
+{
+    const size_t nrec = (size_t)g.NBB * g.NG * g.K * g.NCS;
+    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrec; r += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(r % g.NCS);
+        size_t rest = r / g.NCS;
+        const int t = (int)(rest % g.K);
+        rest /= g.K;
+        const int gamma = (int)(rest % g.NG);
+        const int beta = (int)(rest / g.NG);
+        diag_fill_record(g, beta, gamma, t, ci, table + r * g.RECW);
+    }
+}
+
+__global__ void diag_groups_kernel(DiagGeom g, uint32_t *__restrict__ groups)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) diag_groups(g, groups);
+}
+
+
+int launch_diag_table(const DiagGeom &g, uint32_t *table, uint32_t *groups, hipStream_t st)
+{
+    hipLaunchKernelGGL(diag_groups_kernel, dim3(1), dim3(64), 0, st, g, groups);
+    const size_t nrec = (size_t)g.NBB * g.NG * g.K * g.NCS;
+    const unsigned blocks = (unsigned)((nrec + 255) / 256 < 65535u * 8 ? (nrec + 255) / 256 : 65535u * 8);
+    hipLaunchKernelGGL(diag_table_kernel, dim3(blocks), dim3(256), 0, st, g, table);
+    return (int)hipGetLastError();
+}
+
 struct DiagWorkspace {
-    size_t xp, xp2, ip4, table, groups, total;
+    size_t xp, xp2, ip4, table, groups, compat, total;
 };
+
+// dst[CE][CE] = src[C][C] zero-padded: constant row pitch for the fused epilogue's scalar loads
+__global__ void pad_compat_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int CE)
+{
+    for (int i = threadIdx.x; i < CE * CE; i += blockDim.x) {
+        const int r = i / CE, c = i - r * CE;
+        dst[i] = (r < C && c < C) ? src[r * C + c] : 0.f;
+    }
+}
 
 size_t diag_padded_floats(const DiagGeom &g) { return (size_t)g.FS + (size_t)g.B * g.C * g.plane + 3 * (size_t)g.Wp + 64; }
 
@@ -380,6 +426,7 @@ DiagWorkspace diag_carve(int op, const DiagGeom &g)
     w.ip4 = take(((size_t)g.B * g.plane + 64) * sizeof(F4));
     w.table = take(diag_table_dwords(g) * 4);
     w.groups = take((size_t)g.k * g.k * 4);
+    w.compat = take((size_t)(g.CH * g.NCS) * (g.CH * g.NCS) * 4);
     w.total = off;
     return w;
 }
@@ -435,6 +482,10 @@ void diag_lds(const DiagGeom &g, DiagArgs &a)
 
 extern "C" {
 
+#ifdef MFL_STAMPS
+void mfl_debug_stamps(void *p) { g_stamps = (unsigned long long *)p; }
+#endif
+
 int mfl_version(void) { return MFL_VERSION; }
 
 const char *mfl_error_string(int code)
@@ -488,6 +539,7 @@ int mfl_local_forward(const float *x, const float *img, const float *cd, const f
         DiagArgs da{};
         da.g = dg;
         diag_lds(dg, da);
+        MFL_SET_DBG(da);
         da.xp = (const float *)(base + ws.xp);
         da.ip4 = (const F4 *)(base + ws.ip4);
         da.table = (const uint32_t *)(base + ws.table);
@@ -590,6 +642,7 @@ int mfl_meanfield_forward(const float *unary, const float *img, const float *pos
         DiagArgs da{};
         da.g = dg;
         diag_lds(dg, da);
+        MFL_SET_DBG(da);
         da.ip4 = (const F4 *)(base + ws.ip4);
         da.table = (const uint32_t *)(base + ws.table);
         da.groups = (const uint32_t *)(base + ws.groups);
@@ -598,7 +651,11 @@ int mfl_meanfield_forward(const float *unary, const float *img, const float *pos
         da.unary = unary;
         da.aw = affine_w;
         da.ab = affine_b;
-        da.compat = compat;
+        if (compat) {
+            float *cpad = (float *)(base + ws.compat);
+            hipLaunchKernelGGL(pad_compat_kernel, dim3(1), dim3(kThreads), 0, st, compat, cpad, C, dg.CH * dg.NCS);
+            da.compat = cpad;
+        }
         for (int it = 0; it < iters; ++it) {
             da.xp = qa;
             da.qp_out = qb;

@@ -78,7 +78,26 @@ inline void diag_split(int C, int &CH, int &NCS, int &NGW)
     CH = need <= 8 ? 8 : need <= 10 ? 10 : 11;
 }
 
-MFL_HD int diag_recw(int CH) { return ((2 * CH + 1 + (CH + 1) / 2 + 3) / 4) * 4; }
+// Table record of one (b-block, group, tap, channel split), in dwords (at most 64, so that one
+// vector load puts a whole record into one register, lane j = dword j):
+//   [0, CH)              byte offsets of A        (channels past C repeat the first channel of the split)
+//   [CH, 2CH)            byte offsets of B
+//   [2CH]                header: bit i (i < CH) step i is flagged; bits 16..18 number of slots;
+//                        bit 31 more flagged steps than slots (the per-step columns below are needed)
+//   [2CH+1, +5*slots)    slots, one per flagged step (at most kDiagSlots), 5 dwords each:
+//                          descriptor  step | modeA << 4 | modeB << 6 | (TA + 64) << 8 | (TB + 64) << 16
+//                          byte offsets of the extra and of the shared element of side A, then of side B
+//                        mode 0: side not affected; 1: the run wraps to the next image row at lane T
+//                        (extra element = gap floats further); 2: the row started -T <= k-2 pixels
+//                        before lane 0 (extra element = gap floats earlier).  With p = lane - T and
+//                        D = extra - shared element, pixel n of the side adds D if (mode 1) p >= n or
+//                        (mode 2) p < n.
+//   [xw base, ...)       16-bit pairs: xA | (xB != xA) << 15
+constexpr int kDiagSlots = 3;
+constexpr int kDiagSlotWords = 5;
+MFL_HD int diag_slot_base(int CH) { return 2 * CH + 1; }
+MFL_HD int diag_xw_base(int CH) { return 2 * CH + 1 + kDiagSlotWords * kDiagSlots; }
+MFL_HD int diag_recw(int CH) { return ((diag_xw_base(CH) + (CH + 1) / 2 + 3) / 4) * 4; }
 
 // Returns 0 on success, -1 invalid, -3 too large for 32-bit indexing.
 inline int make_diag_geom(DiagGeom &g, int B, int C, int H, int W, int k, int lds_budget_bytes)
@@ -187,14 +206,20 @@ MFL_HD int diag_groups(const DiagGeom &g, uint32_t *out)
     return n;
 }
 
-// Fill one table record (all CH steps of one (beta, gamma, t, channel split)).
-//   [0, CH)        byte offsets of A        (channels past C repeat the first channel of the split)
-//   [CH, 2CH)      byte offsets of B
-//   [2CH]          bit i set: step i is flagged
-//   [2CH+1, ...)   16-bit pairs: xA | (xB != xA) << 15
+// Side of a flagged step: mode, threshold lane and offset of the extra element (see diag_recw).
+MFL_HD void diag_side(const DiagGeom &g, int off, int x0, int &mode, int &T, int &offE)
+{
+    if (x0 + 63 > g.W - 1) { mode = 1; T = g.W - x0; offE = off + g.gap; }
+    else if (x0 < g.k - 1) { mode = 2; T = -x0; offE = off - g.gap; }
+    else { mode = 0; T = 0; offE = off; }
+}
+
+// Fill one table record (all CH steps of one (beta, gamma, t, channel split)); layout: diag_recw.
 MFL_HD void diag_fill_record(const DiagGeom &g, int beta, int gamma, int t, int ci, uint32_t *rec)
 {
     uint32_t flags = 0;
+    int nslots = 0, nflagged = 0;
+    const int sb = diag_slot_base(g.CH), xb = diag_xw_base(g.CH);
     for (int i = 0; i < g.RECW; ++i) rec[i] = 0;
     for (int i = 0; i < g.CH; ++i) {
         int c = ci * g.CH + i;
@@ -203,11 +228,40 @@ MFL_HD void diag_fill_record(const DiagGeom &g, int beta, int gamma, int t, int 
         const DiagStep st = diag_step(g, beta, gamma, t, c);
         rec[i] = (uint32_t)st.offA * 4u;
         rec[g.CH + i] = (uint32_t)st.offB * 4u;
-        if (st.flagged && !dummy) flags |= 1u << i;
         const uint32_t x16 = (uint32_t)st.xA | ((st.xB != st.xA) ? 0x8000u : 0u);
-        rec[2 * g.CH + 1 + i / 2] |= x16 << (16 * (i & 1));
+        rec[xb + i / 2] |= x16 << (16 * (i & 1));
+        if (st.flagged && !dummy) {
+            flags |= 1u << i;
+            ++nflagged;
+            if (nslots < kDiagSlots) {
+                int mA, tA, eA, mB, tB, eB;
+                diag_side(g, st.offA, st.xA, mA, tA, eA);
+                diag_side(g, st.offB, st.xB, mB, tB, eB);
+                uint32_t *slot = rec + sb + kDiagSlotWords * nslots;
+                slot[0] = (uint32_t)i | ((uint32_t)mA << 4) | ((uint32_t)mB << 6) | ((uint32_t)(tA + 64) << 8) |
+                          ((uint32_t)(tB + 64) << 16);
+                slot[1] = (uint32_t)eA * 4u;
+                slot[2] = (uint32_t)st.offA * 4u;
+                slot[3] = (uint32_t)eB * 4u;
+                slot[4] = (uint32_t)st.offB * 4u;
+                ++nslots;
+            }
+        }
     }
-    rec[2 * g.CH] = flags;
+    // unused slots point at valid elements
+    for (int j = nslots; j < kDiagSlots; ++j) {
+        uint32_t *slot = rec + sb + kDiagSlotWords * j;
+        slot[1] = slot[2] = rec[0];
+        slot[3] = slot[4] = rec[g.CH];
+    }
+    rec[2 * g.CH] = flags | ((uint32_t)nslots << 16) | (nflagged > kDiagSlots ? 0x80000000u : 0u);
+}
+
+// What pixel n of lane `lane` adds to the shared element for one side of a slot (D = extra - shared).
+MFL_HD bool diag_slot_selects(int mode, int T, int lane, int n)
+{
+    const int p = lane - T;
+    return mode == 1 ? p >= n : (mode == 2 ? p < n : false);
 }
 
 }  // namespace mfl

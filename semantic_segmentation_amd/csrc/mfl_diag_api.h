@@ -18,13 +18,13 @@ struct DiagArgs {
     const uint32_t *table;   // diag_fill_record records
     const uint32_t *groups;  // diag_groups list
     const float *pos_w, *col_w;
-    const float *unary, *aw, *ab, *compat;   // mode 0
+    const float *unary, *aw, *ab;             // mode 0
+    const float *compat;                     // mode 0: zero-padded to (CH*NCS)^2, or NULL
     float *logq, *qp_out;                    // mode 0: qp_out has the layout of xp
     float *y;                                // mode 1
+    unsigned long long *dbg;                 // cycle stamps of diagnostic builds (-DMFL_STAMPS), else NULL
 };
 
-// Fills the address table and the weight-group list (diag_groups) on the device.
-int launch_diag_table(const DiagGeom &g, uint32_t *table, uint32_t *groups, hipStream_t st);
 
 #define MFL_DECLARE_DIAG(CHV, KSV) int launch_diag_ch##CHV##_k##KSV(const DiagArgs &a, int mode, hipStream_t st);
 #define MFL_DECLARE_DIAG_K(KSV) MFL_DECLARE_DIAG(8, KSV) MFL_DECLARE_DIAG(10, KSV) MFL_DECLARE_DIAG(11, KSV)
