@@ -157,7 +157,7 @@ def main():
                        "parallelism": f"batch-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                         "kernel": "meanfield_step_kernel", "launch_ms": round(launch_ms, 4),
+                         "kernel": "diag_kernel (fused mean-field step)", "launch_ms": round(launch_ms, 4),
                          "bytes_per_launch": bytes_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -72,6 +72,9 @@ inline bool diag_supported(int C, int H, int W, int k)
 inline void diag_split(int C, int &CH, int &NCS, int &NGW)
 {
     if (C <= 8) { NCS = 1; NGW = 8; CH = 8; return; }
+#ifdef MFL_SPLIT3
+    if (C > 16 && C <= 21) { NCS = 3; NGW = 4; CH = 7; return; }
+#endif
     NCS = C <= 22 ? 2 : 3;
     NGW = NCS == 2 ? 4 : 2;
     const int need = (C + NCS - 1) / NCS;

@@ -608,6 +608,8 @@ int MFL_CAT3(launch_diag_ch, MFL_DIAG_CH, _k, MFL_DIAG_KS)(const DiagArgs &a, in
         if (a.g.NCS == 1) return launch_cfg<CH, KS, 8, 1>(a, mode, st);
         if (a.g.NCS == 2) return launch_cfg<CH, KS, 4, 2>(a, mode, st);
         return launch_cfg<CH, KS, 2, 3>(a, mode, st);
+    } else if constexpr (CH == 7) {
+        return launch_cfg<CH, KS, 4, 3>(a, mode, st);
     } else {
         if (a.g.NCS == 2) return launch_cfg<CH, KS, 4, 2>(a, mode, st);
         if (a.g.NCS == 3) return launch_cfg<CH, KS, 2, 3>(a, mode, st);
