@@ -443,10 +443,7 @@ int dispatch_diag(const DiagArgs &a, int mode, hipStream_t st)
 #define MFL_DIAG_CASE(CHV, KSV) \
     if (a.g.CH == CHV && a.g.k == KSV) return launch_diag_ch##CHV##_k##KSV(a, mode, st);
 #define MFL_DIAG_CASES(KSV) MFL_DIAG_CASE(8, KSV) MFL_DIAG_CASE(10, KSV) MFL_DIAG_CASE(11, KSV)
-#ifdef MFL_SPLIT3
-    MFL_DIAG_CASE(7, 7)
-#endif
-    MFL_DIAG_CASES(3) MFL_DIAG_CASES(5) MFL_DIAG_CASES(7) MFL_DIAG_CASES(9) MFL_DIAG_CASES(11)
+    MFL_DIAG_CASES(3) MFL_DIAG_CASES(5) MFL_DIAG_CASES(7) MFL_DIAG_CASE(5, 9) MFL_DIAG_CASE(5, 11)
 #undef MFL_DIAG_CASES
 #undef MFL_DIAG_CASE
     return MFL_ERR_INVALID_ARGUMENT;

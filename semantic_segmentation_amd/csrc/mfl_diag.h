@@ -59,26 +59,34 @@ struct DiagGeom {
 // Floats of zeroed slack in front of (FS) and behind the padded planes of a batch.
 MFL_HD int diag_front_slack(int k) { return ((2 * k + 2 + 15) / 16) * 16; }
 
+// Channel split: CH channels per wave, NCS waves per group, NGW groups per workgroup.  The
+// accumulator tile of a thread is CH x k registers, so wide windows get narrow channel slices.
+// Returns false when no built configuration fits.
+inline bool diag_split(int C, int k, int &CH, int &NCS, int &NGW)
+{
+    if (k >= 9) {
+        CH = 5;
+        NCS = (C + 4) / 5;
+        if (NCS > 4) return false;
+        NGW = NCS == 1 ? 8 : NCS == 2 ? 4 : 2;
+        return true;
+    }
+    if (C <= 8) { NCS = 1; NGW = 8; CH = 8; return true; }
+    NCS = C <= 22 ? 2 : 3;
+    NGW = NCS == 2 ? 4 : 2;
+    const int need = (C + NCS - 1) / NCS;
+    CH = need <= 8 ? 8 : need <= 10 ? 10 : 11;
+    return true;
+}
+
 inline bool diag_supported(int C, int H, int W, int k)
 {
     if (!(k == 3 || k == 5 || k == 7 || k == 9 || k == 11)) return false;
     if (C > 33 || W < 64 + k || W >= 16384) return false;
     const long long CK = (long long)C * k * k, L = (long long)H * W;
     if (L < 4 * CK) return false;   // too few source pixels per row of the scrambled matrix to fill a wave
-    return true;
-}
-
-// Channel split: CH channels per wave, NCS waves per group.
-inline void diag_split(int C, int &CH, int &NCS, int &NGW)
-{
-    if (C <= 8) { NCS = 1; NGW = 8; CH = 8; return; }
-#ifdef MFL_SPLIT3
-    if (C > 16 && C <= 21) { NCS = 3; NGW = 4; CH = 7; return; }
-#endif
-    NCS = C <= 22 ? 2 : 3;
-    NGW = NCS == 2 ? 4 : 2;
-    const int need = (C + NCS - 1) / NCS;
-    CH = need <= 8 ? 8 : need <= 10 ? 10 : 11;
+    int ch, ncs, ngw;
+    return diag_split(C, k, ch, ncs, ngw);
 }
 
 // Table record of one (b-block, group, tap, channel split), in dwords (at most 64, so that one
@@ -115,7 +123,7 @@ inline int make_diag_geom(DiagGeom &g, int B, int C, int H, int W, int k, int ld
     g.NB = (int)((L + CK - 1) / CK);
     g.NG = C * k;
     g.NBB = (g.NB + k - 1 + 63) / 64;
-    diag_split(C, g.CH, g.NCS, g.NGW);
+    diag_split(C, k, g.CH, g.NCS, g.NGW);
     g.NGB = (g.NG + g.NGW - 1) / g.NGW;
     g.RUN = g.NGW * k;
     g.RUNP = g.RUN | 1;

@@ -28,12 +28,11 @@ struct DiagArgs {
 
 #define MFL_DECLARE_DIAG(CHV, KSV) int launch_diag_ch##CHV##_k##KSV(const DiagArgs &a, int mode, hipStream_t st);
 #define MFL_DECLARE_DIAG_K(KSV) MFL_DECLARE_DIAG(8, KSV) MFL_DECLARE_DIAG(10, KSV) MFL_DECLARE_DIAG(11, KSV)
-MFL_DECLARE_DIAG(7, 7)
 MFL_DECLARE_DIAG_K(3)
 MFL_DECLARE_DIAG_K(5)
 MFL_DECLARE_DIAG_K(7)
-MFL_DECLARE_DIAG_K(9)
-MFL_DECLARE_DIAG_K(11)
+MFL_DECLARE_DIAG(5, 9)
+MFL_DECLARE_DIAG(5, 11)
 
 }  // namespace mfl
 

@@ -21,8 +21,9 @@ _lib.lib.mfl_debug_stamps(ctypes.c_void_p(dbg.data_ptr()))
 S.ops.meanfield_forward(unary, img, pw, cw, k, 1, None, None, compat)
 torch.cuda.synchronize()
 d = dbg.cpu().numpy().reshape(256, 64).astype(np.float64)
-names = {0: "start", 1: "setup", 2: "W0+bar", 40: "loop end", 41: "epilogue"}
-idx = [i for i in range(64) if d[:, i].min() > 0]
+names = {0: "start", 1: "setup", 2: "W0+bar", 40: "loop end", 41: "end", 42: "c0 write", 43: "c0 bar", 44: "c0 pixels", 45: "c0 bar2", 46: "c1 write", 47: "c1 bar", 48: "c1 pixels", 49: "c1 bar2"}
+segs = d[:, 54:60].copy(); d[:, 54:60] = 0
+idx = sorted([i for i in range(64) if d[:, i].min() > 0], key=lambda i: np.median(d[:, i] - d[:, 0]))
 t0 = d[:, 0:1]
 rel = (d - t0)
 prev = 0
@@ -33,3 +34,4 @@ for i in idx:
     nm = names.get(i, f"g{g}:" + ["W(next)", "gather", "barrier"][(i - 3) % 3])
     print(f"{i:4d}  {nm:12s} {cum:12.0f} {cum - prev:12.0f}")
     prev = cum
+print("tap segments (median ticks per workgroup, thread 0): w+record %.0f  corrections %.0f  slot loads %.0f  FMAs+reloads %.0f  between taps %.0f" % tuple(np.median(segs[:, [0, 1, 2, 3, 5]], axis=0)))
