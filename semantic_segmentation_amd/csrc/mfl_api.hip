@@ -470,8 +470,10 @@ void diag_lds(const DiagGeom &g, DiagArgs &a)
 {
     const size_t wbytes = 2 * (size_t)g.TB * g.NBR * g.RUNP * 4;
     const size_t lds = wbytes > 96 * 1024 ? wbytes : 96 * 1024;
-    int rows = (int)(lds / ((size_t)g.C * g.RUNP * 4));
-    if (rows > g.NBR) rows = g.NBR;
+    // the epilogue passes the workgroup's b rows through LDS in equal chunks (fewest that fit)
+    const int max_rows = (int)(lds / ((size_t)g.C * g.RUNP * 4));
+    const int chunks = (g.NBR + max_rows - 1) / max_rows;
+    const int rows = (g.NBR + chunks - 1) / chunks;
     a.lds_bytes = lds;
     a.epi_rows = rows;
 }

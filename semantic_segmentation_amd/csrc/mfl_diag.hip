@@ -38,6 +38,7 @@ struct DiagCfg {
     static constexpr int NSLOT = NBR * RUN;
     static constexpr int S = (NSLOT + NT - 1) / NT;
     static constexpr int SLOTP = NBR * RUNP;
+    static_assert(RUNP > RUN, "the last padded column of the weight table serves as a spare place");
     static constexpr int CE = CH * NCS;
 };
 
@@ -63,7 +64,9 @@ template <int CH, int KS, int NGW, int NCS>
 struct DiagState {
     using Cfg = DiagCfg<CH, KS, NGW, NCS>;
     float acc[CH][KS];
-    int ibase[Cfg::S];          // top-left corner of the pixel's window in the padded image
+    int ioff[Cfg::S];           // byte offset of the top-left corner of the pixel's window in the padded image
+    int lidx[Cfg::S];           // the pixel's place in a tap's LDS weight table (a spare place past the table
+                                // for the thread slots beyond the workgroup's pixels)
     float cr[Cfg::S], cg[Cfg::S], cb[Cfg::S];
 };
 
@@ -75,30 +78,29 @@ struct WeightPhase {
     using Cfg = DiagCfg<CH, KS, NGW, NCS>;
     struct Nb { float r[Cfg::S], g[Cfg::S], b[Cfg::S]; };
 
+    // irsrc: buffer descriptor of the image's padded {r,g,b,0} pixels; toff: tap offset in pixels
     static __device__ __forceinline__ void load(Nb &nb, const DiagState<CH, KS, NGW, NCS> &st,
-                                                const F4 *__restrict__ ip_b, int toff)
+                                                __amdgpu_buffer_rsrc_t irsrc, int toff)
     {
 #pragma unroll
         for (int i = 0; i < Cfg::S; ++i) {
-            const F4 v = ip_b[st.ibase[i] + toff];
+            typedef float f3 __attribute__((ext_vector_type(3)));
+            const f3 v = __builtin_bit_cast(f3, __builtin_amdgcn_raw_buffer_load_b96(irsrc, st.ioff[i], toff * 16, 0));
             nb.r[i] = v.x; nb.g[i] = v.y; nb.b[i] = v.z;
         }
     }
     static __device__ __forceinline__ void store(const Nb &nb, const DiagState<CH, KS, NGW, NCS> &st, float pdw,
                                                  float cw, float *wt_tap)
     {
-        const int tid = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < Cfg::S; ++i) {
-            const int sigma = tid + i * Cfg::NT;
-            const int b_rel = sigma / Cfg::RUN, a_rel = sigma - b_rel * Cfg::RUN;
             const float d0 = st.cr[i] - nb.r[i], d1 = st.cg[i] - nb.g[i], d2 = st.cb[i] - nb.b[i];
             const float cd = fmaf(d2, d2, fmaf(d1, d1, d0 * d0));
-            if (Cfg::NSLOT % Cfg::NT == 0 || sigma < Cfg::NSLOT) wt_tap[b_rel * Cfg::RUNP + a_rel] = fmaf(cd, cw, pdw);
+            wt_tap[st.lidx[i]] = fmaf(cd, cw, pdw);
         }
     }
     static __device__ __forceinline__ void run(const DiagState<CH, KS, NGW, NCS> &st, int p0, int Wp,
-                                               const F4 *__restrict__ ip_b, float pw, float cw, uint32_t gw, float *wt)
+                                               __amdgpu_buffer_rsrc_t irsrc, float pw, float cw, uint32_t gw, float *wt)
     {
 #ifdef MFL_ABL_NO_WEIGHT
         return;
@@ -108,12 +110,12 @@ struct WeightPhase {
         auto pdw = [&](int tt) { const int dy = ky0 + tt - p0; return (float)(dy * dy + dx * dx) * pw; };
         const int toff0 = ky0 * Wp + kx;
         Nb n0, n1;
-        load(n0, st, ip_b, toff0);
+        load(n0, st, irsrc, toff0);
         int tt = 0;
         for (; tt + 1 < nky; tt += 2) {
-            load(n1, st, ip_b, toff0 + (tt + 1) * Wp);
+            load(n1, st, irsrc, toff0 + (tt + 1) * Wp);
             store(n0, st, pdw(tt), cw, wt + tt * Cfg::SLOTP);
-            if (tt + 2 < nky) load(n0, st, ip_b, toff0 + (tt + 2) * Wp);
+            if (tt + 2 < nky) load(n0, st, irsrc, toff0 + (tt + 2) * Wp);
             store(n1, st, pdw(tt + 1), cw, wt + (tt + 1) * Cfg::SLOTP);
         }
         if (tt < nky) store(n0, st, pdw(tt), cw, wt + tt * Cfg::SLOTP);
@@ -155,40 +157,44 @@ struct SlotSide {
 // accumulators of the step that matches, and an immediate exit for an empty slot (step >= 11).
 // Layout of a block: tests first (compare + branch not taken for the steps that do not match, so an
 // unmatched step costs two scalar instructions and no jump), then the per-step bodies.
+// Layout of a block: tests first (compare + branch not taken for the steps that do not match, so an
+// unmatched step costs two scalar instructions and no jump), then the per-step bodies.  Only the CH
+// steps of this translation unit are listed.
+#if MFL_DIAG_CH == 5
+#define MFL_CORR_LIST(M) M(0) M(1) M(2) M(3) M(4)
+#elif MFL_DIAG_CH == 8
+#define MFL_CORR_LIST(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+#elif MFL_DIAG_CH == 10
+#define MFL_CORR_LIST(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9)
+#elif MFL_DIAG_CH == 11
+#define MFL_CORR_LIST(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10)
+#else
+#error "no correction step list for this MFL_DIAG_CH"
+#endif
 #define MFL_CORR_TEST(I) "s_cmp_eq_u32 %[st], " #I "\n\ts_cbranch_scc1 2" #I "f\n\t"
-#define MFL_CORR_TESTS                                                                                       \
-    MFL_CORR_TEST(0) MFL_CORR_TEST(1) MFL_CORR_TEST(2) MFL_CORR_TEST(3) MFL_CORR_TEST(4) MFL_CORR_TEST(5)     \
-    MFL_CORR_TEST(6) MFL_CORR_TEST(7) MFL_CORR_TEST(8) MFL_CORR_TEST(9) MFL_CORR_TEST(10) "s_branch 9f\n"
 #define MFL_CORR_BODY2(I) \
     "2" #I ":\n\tv_add_f32 %[a" #I "], %[a" #I "], %[t0]\n\tv_add_f32 %[b" #I "], %[b" #I "], %[t1]\n\ts_branch 9f\n"
 #define MFL_CORR_BODY1(I) "2" #I ":\n\tv_add_f32 %[a" #I "], %[a" #I "], %[t0]\n\ts_branch 9f\n"
-#define MFL_CORR_ACC(X, r)                                                                                          \
-    [X##0] "+v"(r[0]), [X##1] "+v"(r[1]), [X##2] "+v"(r[2]), [X##3] "+v"(r[3]), [X##4] "+v"(r[4]), [X##5] "+v"(r[5]), \
-        [X##6] "+v"(r[6]), [X##7] "+v"(r[7]), [X##8] "+v"(r[8]), [X##9] "+v"(r[9]), [X##10] "+v"(r[10])
+#define MFL_CORR_OPA(I) [a##I] "+v"(ra[I]),
+#define MFL_CORR_OPB(I) [b##I] "+v"(rb[I]),
 
-// pixels N0 and N0 + 1 (same side); a*/b*: the 11 step rows of the two pixels' accumulators
+// pixels N0 and N0 + 1 (same side); a*/b*: the step rows of the two pixels' accumulators
 #define MFL_CORR_PAIR(N0, N1)                                                                                       \
     asm volatile("s_cmp_ge_u32 %[st], 11\n\ts_cbranch_scc1 9f\n\t"                                                  \
                  "v_cmp_le_i32 vcc, " #N0 ", %[p]\n\tv_cndmask_b32 %[t0], %[dlt], %[dge], vcc\n\t"                   \
                  "v_mul_f32 %[t0], %[w0], %[t0]\n\t"                                                                 \
                  "v_cmp_le_i32 vcc, " #N1 ", %[p]\n\tv_cndmask_b32 %[t1], %[dlt], %[dge], vcc\n\t"                   \
                  "v_mul_f32 %[t1], %[w1], %[t1]\n\t"                                                                 \
-                 MFL_CORR_TESTS                                                                                      \
-                 MFL_CORR_BODY2(0) MFL_CORR_BODY2(1) MFL_CORR_BODY2(2) MFL_CORR_BODY2(3) MFL_CORR_BODY2(4)           \
-                 MFL_CORR_BODY2(5) MFL_CORR_BODY2(6) MFL_CORR_BODY2(7) MFL_CORR_BODY2(8) MFL_CORR_BODY2(9)           \
-                 MFL_CORR_BODY2(10) "9:"                                                                             \
-                 : MFL_CORR_ACC(a, ra), MFL_CORR_ACC(b, rb), [t0] "=&v"(t0), [t1] "=&v"(t1)                          \
+                 MFL_CORR_LIST(MFL_CORR_TEST) "s_branch 9f\n" MFL_CORR_LIST(MFL_CORR_BODY2) "9:"                      \
+                 : MFL_CORR_LIST(MFL_CORR_OPA) MFL_CORR_LIST(MFL_CORR_OPB)[t0] "=&v"(t0), [t1] "=&v"(t1)             \
                  : [w0] "v"(w0), [w1] "v"(w1), [dlt] "v"(sd.d_lt), [dge] "v"(sd.d_ge), [p] "v"(sd.p), [st] "s"(step) \
                  : "vcc", "scc")
 #define MFL_CORR_ONE(N0)                                                                                            \
     asm volatile("s_cmp_ge_u32 %[st], 11\n\ts_cbranch_scc1 9f\n\t"                                                  \
                  "v_cmp_le_i32 vcc, " #N0 ", %[p]\n\tv_cndmask_b32 %[t0], %[dlt], %[dge], vcc\n\t"                   \
                  "v_mul_f32 %[t0], %[w0], %[t0]\n\t"                                                                 \
-                 MFL_CORR_TESTS                                                                                      \
-                 MFL_CORR_BODY1(0) MFL_CORR_BODY1(1) MFL_CORR_BODY1(2) MFL_CORR_BODY1(3) MFL_CORR_BODY1(4)           \
-                 MFL_CORR_BODY1(5) MFL_CORR_BODY1(6) MFL_CORR_BODY1(7) MFL_CORR_BODY1(8) MFL_CORR_BODY1(9)           \
-                 MFL_CORR_BODY1(10) "9:"                                                                             \
-                 : MFL_CORR_ACC(a, ra), [t0] "=&v"(t0)                                                               \
+                 MFL_CORR_LIST(MFL_CORR_TEST) "s_branch 9f\n" MFL_CORR_LIST(MFL_CORR_BODY1) "9:"                      \
+                 : MFL_CORR_LIST(MFL_CORR_OPA)[t0] "=&v"(t0)                                                         \
                  : [w0] "v"(w0), [dlt] "v"(sd.d_lt), [dge] "v"(sd.d_ge), [p] "v"(sd.p), [st] "s"(step)               \
                  : "vcc", "scc")
 
@@ -247,7 +253,7 @@ struct Loop {
     __amdgpu_buffer_rsrc_t rsrc;
     const uint32_t *__restrict__ table;    // records of this wave's (b-block, group, channel split), tap 0
     const uint32_t *__restrict__ groups;
-    const F4 *__restrict__ ip_b;
+    __amdgpu_buffer_rsrc_t irsrc;           // the image's padded {r,g,b,0} pixels
     float *lds;
     float pw, cw;
     int ngroups, TB, trec, recw;            // trec: dwords between the records of consecutive taps
@@ -483,7 +489,7 @@ struct Loop {
             for (int tt = 0; tt < ntap; ++tt) {
                 typename WP::Nb nb;
 #ifndef MFL_ABL_NO_WEIGHT
-                if (tt < nkyn) WP::load(nb, st, ip_b, (ky0n + tt) * Wp + kxn);
+                if (tt < nkyn) WP::load(nb, st, irsrc, (ky0n + tt) * Wp + kxn);
 #endif
 #ifndef MFL_ABL_NO_GATHER
                 if (live && tt < nky) tap<SA>(wt + tt * Cfg::SLOTP);
@@ -523,7 +529,7 @@ struct Loop {
             for (int i = 0; i < CH; ++i) v.B[i] = buf_load(rsrc, voff, rec_word(rec_use, CH + i));
             load_slots(rec_use);
         }
-        WeightPhase<CH, KS, NGW, NCS>::run(st, p0, Wp, ip_b, pw, cw, groups[0], lds);
+        WeightPhase<CH, KS, NGW, NCS>::run(st, p0, Wp, irsrc, pw, cw, groups[0], lds);
         __syncthreads();
         MFL_STAMP(2);
         classes<0>(0);
@@ -576,12 +582,15 @@ diag_kernel(DiagGeom g, int epi_rows, const float *__restrict__ xp, const F4 *__
         const bool valid = bb >= 0 && aa < CK && l < L;
         const int lc = valid ? (int)l : 0;
         const int y = lc / W, x = lc - y * W;
-        st.ibase[i] = y * Wp + x;
-        const F4 c = ip_b[st.ibase[i] + ctr_off];
+        const int ibase = y * Wp + x;
+        st.ioff[i] = ibase * 16;
+        st.lidx[i] = sigma < Cfg::NSLOT ? b_rel * Cfg::RUNP + a_rel : Cfg::SLOTP - 1;
+        const F4 c = ip_b[ibase + ctr_off];
         st.cr[i] = c.x; st.cg[i] = c.y; st.cb[i] = c.z;
     }
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ip_b, 0, 0x7fffffff, 0x00020000);
 
-    Loop<CH, KS, NGW, NCS> loop{st, rsrc, table + diag_record_index(g, beta, live ? gamma : 0, 0, ci), groups, ip_b, lds,
+    Loop<CH, KS, NGW, NCS> loop{st, rsrc, table + diag_record_index(g, beta, live ? gamma : 0, 0, ci), groups, irsrc, lds,
                                 pw, cw, g.ngroups, g.TB, g.NCS * g.RECW, g.RECW, g.p0, Wp, W, g.gap * 4, gi, lane, live,
                                 dbg};
     MFL_STAMP(1);
