@@ -237,15 +237,6 @@ __device__ __forceinline__ void corr_one(const AccCol &ra, float w0, const SlotS
     else MFL_CORR_ONE(10);
 }
 
-// A wave-uniform value the compiler must treat as per-lane (the rare per-step path below branches on
-// it: EXEC-masked code keeps its accumulators in place).
-__device__ __forceinline__ int per_lane(int uniform)
-{
-    int v;
-    asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform));
-    return v;
-}
-
 template <int CH, int KS, int NGW, int NCS>
 struct Loop {
     using Cfg = DiagCfg<CH, KS, NGW, NCS>;
@@ -337,70 +328,61 @@ struct Loop {
     __device__ __forceinline__ void correct(uint32_t hdr, const float (&w)[KS])
     {
         static_assert(CH <= 11, "the correction blocks name 11 step rows");
-        if (!(hdr & 0x80000000u)) {
-            const int nslots = (hdr >> 16) & 7;
-            constexpr int sb = 2 * CH + 1;
-            float dummy[11] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int nslots = (hdr >> 16) & 7;
+        constexpr int sb = 2 * CH + 1;
+        float dummy[11] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < kDiagSlots; ++j) {
-                // an empty slot keeps step = 15: its blocks exit at once
-                int step = 15;
-                SlotSide sa{0.f, 0.f, 0}, sb_{0.f, 0.f, 0};
-                if (j < nslots) {
-                    const uint32_t desc = rec_word(rec_use, sb + kDiagSlotWords * j);
-                    step = desc & 15;
-                    sa = slot_side((desc >> 4) & 3, (int)((desc >> 8) & 127) - 64, v.FA[j], v.EA[j]);
-                    if constexpr (SA > 0) sb_ = slot_side((desc >> 6) & 3, (int)((desc >> 16) & 127) - 64, v.FB[j], v.EB[j]);
-                }
-                correct_side<0, KS - SA>(w, sa, step, dummy);
-                if constexpr (SA > 0) correct_side<KS - SA, KS>(w, sb_, step, dummy);
+        for (int j = 0; j < kDiagSlots; ++j) {
+            // an empty slot keeps step = 15: its blocks exit at once
+            int step = 15;
+            SlotSide sa{0.f, 0.f, 0}, sb_{0.f, 0.f, 0};
+            if (j < nslots) {
+                const uint32_t desc = rec_word(rec_use, sb + kDiagSlotWords * j);
+                step = desc & 15;
+                sa = slot_side((desc >> 4) & 3, (int)((desc >> 8) & 127) - 64, v.FA[j], v.EA[j]);
+                if constexpr (SA > 0) sb_ = slot_side((desc >> 6) & 3, (int)((desc >> 16) & 127) - 64, v.FB[j], v.EB[j]);
             }
-        } else {
-            overflow_steps<SA>(std::make_integer_sequence<int, CH>{}, hdr, w);
+            correct_side<0, KS - SA>(w, sa, step, dummy);
+            if constexpr (SA > 0) correct_side<KS - SA, KS>(w, sb_, step, dummy);
         }
+        if (hdr & 0x80000000u) overflow_loop<SA>(hdr, w, dummy);
     }
 
-    template <int SA, int I>
-    __device__ __forceinline__ void overflow_step(const float (&w)[KS])
+    // A record with more flagged steps than slots (narrow images): the steps past the slots are
+    // walked in a wave-uniform loop.  Each one derives the slot description from the step's column
+    // word, loads its four elements on demand and goes through the same correction blocks.
+    template <int SA>
+    __device__ __forceinline__ void overflow_loop(uint32_t hdr, const float (&w)[KS], float (&dummy)[11])
     {
-        asm volatile("; step %0" ::"n"(I));
         const int voff = lane * 4;
-        const uint32_t x16 = (rec_word(rec_use, diag_xw_base(CH) + I / 2) >> (16 * (I & 1))) & 0xffffu;
-        const int xA = x16 & 0x7fff;
-        const int xB = (x16 & 0x8000) ? (xA + 1 == W ? 0 : xA + 1) : xA;
-        const uint32_t oA = rec_word(rec_use, I), oB = rec_word(rec_use, CH + I);
-        int pA = xA + lane;
-        const bool wrA = pA >= W;
-        pA -= wrA ? W : 0;
-        const int vA = voff + (wrA ? gap4 : 0);
-        const float Ft = buf_load(rsrc, voff, oA);
-        const float At = buf_load(rsrc, vA, oA);
-        const float Xt = buf_load(rsrc, vA, oA - (uint32_t)gap4);
-        float Gt = 0.f, Bt = 0.f, Yt = 0.f;
-        int pB = 0;
-        if constexpr (SA > 0) {
-            pB = xB + lane;
-            const bool wrB = pB >= W;
-            pB -= wrB ? W : 0;
-            const int vB = voff + (wrB ? gap4 : 0);
-            Gt = buf_load(rsrc, voff, oB);
-            Bt = buf_load(rsrc, vB, oB);
-            Yt = buf_load(rsrc, vB, oB - (uint32_t)gap4);
-        }
-        const float dA0 = At - Ft, dA1 = Xt - Ft;
-        float dB0 = 0.f, dB1 = 0.f;
-        if constexpr (SA > 0) { dB0 = Bt - Gt; dB1 = Yt - Gt; }
+        uint32_t m = hdr & 0xffffu;
 #pragma unroll
-        for (int n = 0; n < KS; ++n) {
-            const float dv = (n < KS - SA) ? ((pA < n) ? dA1 : dA0) : ((pB < n) ? dB1 : dB0);
-            st.acc[I][n] = fmaf(w[n], dv, st.acc[I][n]);
+        for (int j = 0; j < kDiagSlots; ++j) m &= m - 1;
+        while (m) {
+            const int i = __builtin_ctz(m);
+            m &= m - 1;
+            const uint32_t x16 = (rec_word(rec_use, diag_xw_base(CH) + (i >> 1)) >> (16 * (i & 1))) & 0xffffu;
+            const int xA = x16 & 0x7fff;
+            const int xB = (x16 & 0x8000) ? (xA + 1 == W ? 0 : xA + 1) : xA;
+            const uint32_t oA = rec_word(rec_use, i), oB = rec_word(rec_use, CH + i);
+            auto side = [&](uint32_t off, int x0, int &mode, int &T, uint32_t &offE) {
+                if (x0 + 63 > W - 1) { mode = 1; T = W - x0; offE = off + (uint32_t)gap4; }
+                else if (x0 < KS - 1) { mode = 2; T = -x0; offE = off - (uint32_t)gap4; }
+                else { mode = 0; T = 0; offE = off; }
+            };
+            int mA, tA, mB = 0, tB = 0;
+            uint32_t eA, eB = oB;
+            side(oA, xA, mA, tA, eA);
+            const float FAv = buf_load(rsrc, voff, oA), EAv = buf_load(rsrc, voff, eA);
+            const SlotSide sa = slot_side(mA, tA, FAv, EAv);
+            correct_side<0, KS - SA>(w, sa, i, dummy);
+            if constexpr (SA > 0) {
+                side(oB, xB, mB, tB, eB);
+                const float FBv = buf_load(rsrc, voff, oB), EBv = buf_load(rsrc, voff, eB);
+                const SlotSide sb_ = slot_side(mB, tB, FBv, EBv);
+                correct_side<KS - SA, KS>(w, sb_, i, dummy);
+            }
         }
-    }
-    template <int SA, int... I>
-    __device__ __forceinline__ void overflow_steps(std::integer_sequence<int, I...>, uint32_t hdr, const float (&w)[KS])
-    {
-        const int hv = per_lane((int)hdr);
-        ((((hv >> I) & 1) ? (overflow_step<SA, I>(w), 0) : 0), ...);
     }
 
 #ifdef MFL_STAMPS

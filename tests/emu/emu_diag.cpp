@@ -68,26 +68,34 @@ extern "C" int emu_diag_local_forward(const float *x, const float *img, float pw
                                         const bool useA = s + n < k;
                                         const int off = (int)(rec[useA ? i : g.CH + i] / 4);
                                         int idx = off + lane;
-                                        if (flagged && !(hdr & 0x80000000u)) {
-                                            // slot path: the shared element plus, where selected, the
-                                            // difference to the slot's extra element
+                                        if (flagged) {
+                                            // a slot holds the step: the shared element plus, where
+                                            // selected, the difference to the slot's extra element;
+                                            // steps past the slots (overflow records): per-lane rule
                                             const int nslots = (hdr >> 16) & 7;
                                             const uint32_t *slot = nullptr;
                                             for (int j = 0; j < nslots; ++j)
                                                 if ((int)(rec[diag_slot_base(g.CH) + kDiagSlotWords * j] & 15) == i)
                                                     slot = rec + diag_slot_base(g.CH) + kDiagSlotWords * j;
-                                            if (!slot) return -11;
-                                            const int mode = useA ? (slot[0] >> 4) & 3 : (slot[0] >> 6) & 3;
-                                            const int T = (int)((slot[0] >> (useA ? 8 : 16)) & 127) - 64;
-                                            if ((int)(slot[useA ? 2 : 4] / 4) != off) return -12;
-                                            if (diag_slot_selects(mode, T, lane, n)) idx = (int)(slot[useA ? 1 : 3] / 4) + lane;
-                                        } else if (flagged) {
-                                            const uint32_t x16 =
-                                                (rec[diag_xw_base(g.CH) + i / 2] >> (16 * (i & 1))) & 0xffff;
-                                            const int xA = x16 & 0x7fff;
-                                            int xB = xA;
-                                            if (x16 & 0x8000) xB = (xA + 1 == W) ? 0 : xA + 1;
-                                            idx = diag_lane_index(g, off, useA ? xA : xB, lane, n);
+                                            if (!slot && !(hdr & 0x80000000u)) return -11;
+                                            if (slot) {
+                                                const int mode = useA ? (slot[0] >> 4) & 3 : (slot[0] >> 6) & 3;
+                                                const int T = (int)((slot[0] >> (useA ? 8 : 16)) & 127) - 64;
+                                                if ((int)(slot[useA ? 2 : 4] / 4) != off) return -12;
+                                                if (diag_slot_selects(mode, T, lane, n))
+                                                    idx = (int)(slot[useA ? 1 : 3] / 4) + lane;
+                                            } else {
+                                                const uint32_t x16 =
+                                                    (rec[diag_xw_base(g.CH) + i / 2] >> (16 * (i & 1))) & 0xffff;
+                                                const int xA = x16 & 0x7fff;
+                                                int xB = xA;
+                                                if (x16 & 0x8000) xB = (xA + 1 == W) ? 0 : xA + 1;
+                                                // the device derives the side description from the column word
+                                                int mode, T, offE;
+                                                diag_side(g, off, useA ? xA : xB, mode, T, offE);
+                                                idx = (diag_slot_selects(mode, T, lane, n) ? offE : off) + lane;
+                                                if (idx != diag_lane_index(g, off, useA ? xA : xB, lane, n)) return -13;
+                                            }
                                         }
                                         // tap weight
                                         const int ny = py + ky - g.p0, nx = px + kx - g.p0;
