@@ -12,7 +12,8 @@ data path); the time is the maximum over ranks between two barriers.
 
 Prints one JSON line: metric = mean-field iter*Mpixel/s over the whole job, plus
   roofline      the fused step kernel against the HBM roofline: algorithmic bytes per launch
-                ((12*L + 12) B per pixel-iteration) / its average duration measured with HIP events
+                ((12*L + 12) B per pixel-iteration) / its average duration measured with HIP events;
+                traffic = memory-side bytes per launch from the committed PMC passes
   cpu_baseline  the CPU oracle (a port of the reference's arithmetic) timed on this host's cores
                 on a bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -66,6 +67,17 @@ def cpu_baseline():
             "cores": O.num_threads(), "kind": "port",
             "sample": f"{sample} of the {BATCH_PER_GPU} images x {ITERS} iterations, C oracle with OpenMP, "
                       f"{dt:.1f} s"}
+
+
+def measured_traffic():
+    """Memory-side bytes per launch of the fused step kernel from the committed PMC passes
+    (profiles/traffic.json says how they were collected and corrected); None when absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        return int(t["traffic_bytes_per_launch"]), t["sources"]
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def main():
@@ -141,6 +153,7 @@ def main():
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
 
     if rank == 0:
+        traffic, traffic_src = measured_traffic()
         total_pixel_iters = ITERS * BATCH_PER_GPU * world * HEIGHT * WIDTH * args.steps
         line = {
             "metric": "mean-field iter*Mpixel/s (node)",
@@ -156,7 +169,8 @@ def main():
                        "batch_per_gpu": BATCH_PER_GPU, "global_batch": BATCH_PER_GPU * world,
                        "parallelism": f"batch-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes per launch (PMC, committed passes)", "traffic_source": traffic_src,
                          "kernel": "diag_kernel (fused mean-field step)", "launch_ms": round(launch_ms, 4),
                          "bytes_per_launch": bytes_per_launch},
         }
