@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 LABELS, HEIGHT, WIDTH, WINDOW, ITERS, BATCH_PER_GPU = 21, 512, 512, 7, 10, 8
 POS_W, COL_W = -0.004, -0.003
 HBM_PEAK_GBPS = 8000.0
+VALU_PEAK_TFLOPS = 157.0      # fp32 vector peak
 IMAGENET_MEAN = np.array([0.485, 0.456, 0.406], np.float32).reshape(3, 1, 1)
 IMAGENET_STD = np.array([0.229, 0.224, 0.225], np.float32).reshape(3, 1, 1)
 
@@ -151,6 +152,9 @@ def main():
     pixels = BATCH_PER_GPU * HEIGHT * WIDTH
     bytes_per_launch = (12 * LABELS + 12) * pixels
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+    # algorithmic flops per pixel-iteration: gather MACs + weight build + LxL compat + two softmax passes
+    flops_per_launch = (2 * LABELS * WINDOW ** 2 + 11 * WINDOW ** 2 + 2 * LABELS ** 2 + 8 * LABELS) * pixels
+    tflops = flops_per_launch / (launch_ms * 1e-3) / 1e12
 
     if rank == 0:
         traffic, traffic_src = measured_traffic()
@@ -172,7 +176,9 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "traffic_unit": "bytes per launch (PMC, committed passes)", "traffic_source": traffic_src,
                          "kernel": "diag_kernel (fused mean-field step)", "launch_ms": round(launch_ms, 4),
-                         "bytes_per_launch": bytes_per_launch},
+                         "bytes_per_launch": bytes_per_launch,
+                         "valu": {"achieved": round(tflops, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(tflops / VALU_PEAK_TFLOPS, 4)}},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
