@@ -152,90 +152,63 @@ struct SlotSide {
 
 // The step a slot corrects is known at run time only, but the accumulators must be reached through
 // constant register names.  A C++ branch per step around accumulator updates makes the compiler copy
-// the accumulators on every path; these blocks keep the whole decision inside one asm statement
-// instead: a scalar compare-and-branch chain over the 11 possible steps, in-place v_add on the
-// accumulators of the step that matches, and an immediate exit for an empty slot (step >= 11).
-// Layout of a block: tests first (compare + branch not taken for the steps that do not match, so an
-// unmatched step costs two scalar instructions and no jump), then the per-step bodies.
-// Layout of a block: tests first (compare + branch not taken for the steps that do not match, so an
-// unmatched step costs two scalar instructions and no jump), then the per-step bodies.  Only the CH
-// steps of this translation unit are listed.
+// the accumulators on every path, so the whole decision sits inside ONE asm statement per slot: an
+// immediate exit for an empty slot (step >= CH), the per-pixel selection of what to add
+// (t[n] = p[n] >= n ? d_ge[n] : d_lt[n]), then a computed jump (s_getpc + step * body size) into a
+// table of per-step bodies, each k in-place v_fmac on the accumulators of that step and a branch out.
+// The bodies must keep the fixed size MFL_CORR_STRIDE = 4*k + 4 bytes (k 4-byte VOP2 + s_branch).
 #if MFL_DIAG_CH == 5
 #define MFL_CORR_LIST(M) M(0) M(1) M(2) M(3) M(4)
+#define MFL_CORR_CH "5"
 #elif MFL_DIAG_CH == 8
 #define MFL_CORR_LIST(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+#define MFL_CORR_CH "8"
 #elif MFL_DIAG_CH == 10
 #define MFL_CORR_LIST(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9)
+#define MFL_CORR_CH "10"
 #elif MFL_DIAG_CH == 11
 #define MFL_CORR_LIST(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10)
+#define MFL_CORR_CH "11"
 #else
 #error "no correction step list for this MFL_DIAG_CH"
 #endif
-#define MFL_CORR_TEST(I) "s_cmp_eq_u32 %[st], " #I "\n\ts_cbranch_scc1 2" #I "f\n\t"
-#define MFL_CORR_BODY2(I) \
-    "2" #I ":\n\tv_add_f32 %[a" #I "], %[a" #I "], %[t0]\n\tv_add_f32 %[b" #I "], %[b" #I "], %[t1]\n\ts_branch 9f\n"
-#define MFL_CORR_BODY1(I) "2" #I ":\n\tv_add_f32 %[a" #I "], %[a" #I "], %[t0]\n\ts_branch 9f\n"
-#define MFL_CORR_OPA(I) [a##I] "+v"(ra[I]),
-#define MFL_CORR_OPB(I) [b##I] "+v"(rb[I]),
-
-// pixels N0 and N0 + 1 (same side); a*/b*: the step rows of the two pixels' accumulators
-#define MFL_CORR_PAIR(N0, N1)                                                                                       \
-    asm volatile("s_cmp_ge_u32 %[st], 11\n\ts_cbranch_scc1 9f\n\t"                                                  \
-                 "v_cmp_le_i32 vcc, " #N0 ", %[p]\n\tv_cndmask_b32 %[t0], %[dlt], %[dge], vcc\n\t"                   \
-                 "v_mul_f32 %[t0], %[w0], %[t0]\n\t"                                                                 \
-                 "v_cmp_le_i32 vcc, " #N1 ", %[p]\n\tv_cndmask_b32 %[t1], %[dlt], %[dge], vcc\n\t"                   \
-                 "v_mul_f32 %[t1], %[w1], %[t1]\n\t"                                                                 \
-                 MFL_CORR_LIST(MFL_CORR_TEST) "s_branch 9f\n" MFL_CORR_LIST(MFL_CORR_BODY2) "9:"                      \
-                 : MFL_CORR_LIST(MFL_CORR_OPA) MFL_CORR_LIST(MFL_CORR_OPB)[t0] "=&v"(t0), [t1] "=&v"(t1)             \
-                 : [w0] "v"(w0), [w1] "v"(w1), [dlt] "v"(sd.d_lt), [dge] "v"(sd.d_ge), [p] "v"(sd.p), [st] "s"(step) \
-                 : "vcc", "scc")
-#define MFL_CORR_ONE(N0)                                                                                            \
-    asm volatile("s_cmp_ge_u32 %[st], 11\n\ts_cbranch_scc1 9f\n\t"                                                  \
-                 "v_cmp_le_i32 vcc, " #N0 ", %[p]\n\tv_cndmask_b32 %[t0], %[dlt], %[dge], vcc\n\t"                   \
-                 "v_mul_f32 %[t0], %[w0], %[t0]\n\t"                                                                 \
-                 MFL_CORR_LIST(MFL_CORR_TEST) "s_branch 9f\n" MFL_CORR_LIST(MFL_CORR_BODY1) "9:"                      \
-                 : MFL_CORR_LIST(MFL_CORR_OPA)[t0] "=&v"(t0)                                                         \
-                 : [w0] "v"(w0), [dlt] "v"(sd.d_lt), [dge] "v"(sd.d_ge), [p] "v"(sd.p), [st] "s"(step)               \
-                 : "vcc", "scc")
-
-// ra / rb: references to the accumulators acc[0..10][n] of pixel n (rows past CH: dummies)
-struct AccCol {
-    float *r[11];
-    __device__ __forceinline__ float &operator[](int i) const { return *r[i]; }
-};
-
-template <int N0>
-__device__ __forceinline__ void corr_pair(const AccCol &ra, const AccCol &rb, float w0, float w1, const SlotSide &sd,
-                                          int step)
-{
-    float t0, t1;
-    if constexpr (N0 == 0) MFL_CORR_PAIR(0, 1);
-    else if constexpr (N0 == 1) MFL_CORR_PAIR(1, 2);
-    else if constexpr (N0 == 2) MFL_CORR_PAIR(2, 3);
-    else if constexpr (N0 == 3) MFL_CORR_PAIR(3, 4);
-    else if constexpr (N0 == 4) MFL_CORR_PAIR(4, 5);
-    else if constexpr (N0 == 5) MFL_CORR_PAIR(5, 6);
-    else if constexpr (N0 == 6) MFL_CORR_PAIR(6, 7);
-    else if constexpr (N0 == 7) MFL_CORR_PAIR(7, 8);
-    else if constexpr (N0 == 8) MFL_CORR_PAIR(8, 9);
-    else MFL_CORR_PAIR(9, 10);
-}
-template <int N0>
-__device__ __forceinline__ void corr_one(const AccCol &ra, float w0, const SlotSide &sd, int step)
-{
-    float t0;
-    if constexpr (N0 == 0) MFL_CORR_ONE(0);
-    else if constexpr (N0 == 1) MFL_CORR_ONE(1);
-    else if constexpr (N0 == 2) MFL_CORR_ONE(2);
-    else if constexpr (N0 == 3) MFL_CORR_ONE(3);
-    else if constexpr (N0 == 4) MFL_CORR_ONE(4);
-    else if constexpr (N0 == 5) MFL_CORR_ONE(5);
-    else if constexpr (N0 == 6) MFL_CORR_ONE(6);
-    else if constexpr (N0 == 7) MFL_CORR_ONE(7);
-    else if constexpr (N0 == 8) MFL_CORR_ONE(8);
-    else if constexpr (N0 == 9) MFL_CORR_ONE(9);
-    else MFL_CORR_ONE(10);
-}
+#if MFL_DIAG_KS == 3
+#define MFL_KS_LIST(M, I) M(I, 0) M(I, 1) M(I, 2)
+#define MFL_CORR_STRIDE "16"
+#elif MFL_DIAG_KS == 5
+#define MFL_KS_LIST(M, I) M(I, 0) M(I, 1) M(I, 2) M(I, 3) M(I, 4)
+#define MFL_CORR_STRIDE "24"
+#elif MFL_DIAG_KS == 7
+#define MFL_KS_LIST(M, I) M(I, 0) M(I, 1) M(I, 2) M(I, 3) M(I, 4) M(I, 5) M(I, 6)
+#define MFL_CORR_STRIDE "32"
+#elif MFL_DIAG_KS == 9
+#define MFL_KS_LIST(M, I) M(I, 0) M(I, 1) M(I, 2) M(I, 3) M(I, 4) M(I, 5) M(I, 6) M(I, 7) M(I, 8)
+#define MFL_CORR_STRIDE "40"
+#elif MFL_DIAG_KS == 11
+#define MFL_KS_LIST(M, I) M(I, 0) M(I, 1) M(I, 2) M(I, 3) M(I, 4) M(I, 5) M(I, 6) M(I, 7) M(I, 8) M(I, 9) M(I, 10)
+#define MFL_CORR_STRIDE "48"
+#else
+#error "no pixel list for this MFL_DIAG_KS"
+#endif
+#define MFL_CORR_SEL(I, N) \
+    "v_cmp_le_i32 vcc, " #N ", %[p" #N "]\n\tv_cndmask_b32 %[t" #N "], %[dl" #N "], %[dg" #N "], vcc\n\t"
+#define MFL_CORR_FMA(I, N) "v_fmac_f32_e32 %[a" #I "_" #N "], %[w" #N "], %[t" #N "]\n\t"
+#define MFL_CORR_BODY(I) MFL_KS_LIST(MFL_CORR_FMA, I) "s_branch 9f\n\t"
+#define MFL_CORR_ACC(I, N) [a##I##_##N] "+v"(st.acc[I][N]),
+#define MFL_CORR_ACCS(I) MFL_KS_LIST(MFL_CORR_ACC, I)
+#define MFL_CORR_TMP(I, N) [t##N] "=&v"(t[N]),
+#define MFL_CORR_IN(I, N) [w##N] "v"(w[N]), [p##N] "v"(pp[N]), [dl##N] "v"(dl[N]), [dg##N] "v"(dg[N]),
+// s[96:97] hold the jump target: named registers because the two halves are added separately
+#define MFL_CORR_SLOT()                                                                                   \
+    asm volatile("s_cmp_ge_u32 %[st], " MFL_CORR_CH "\n\ts_cbranch_scc1 9f\n\t"                          \
+                 MFL_KS_LIST(MFL_CORR_SEL, 0)                                                             \
+                 "s_mul_i32 %[tmp], %[st], " MFL_CORR_STRIDE "\n\ts_add_u32 %[tmp], %[tmp], 12\n\t"      \
+                 "s_getpc_b64 s[96:97]\n\ts_add_u32 s96, s96, %[tmp]\n\ts_addc_u32 s97, s97, 0\n\t"     \
+                 "s_setpc_b64 s[96:97]\n\t"                                                               \
+                 MFL_CORR_LIST(MFL_CORR_BODY) "9:"                                                        \
+                 : MFL_CORR_LIST(MFL_CORR_ACCS) MFL_KS_LIST(MFL_CORR_TMP, 0)[tmp] "=&s"(tmp)              \
+                 : MFL_KS_LIST(MFL_CORR_IN, 0)[st] "s"(step)                                              \
+                 : "vcc", "scc", "s96", "s97")
 
 template <int CH, int KS, int NGW, int NCS>
 struct Loop {
@@ -293,23 +266,23 @@ struct Loop {
         }
     }
 
-    __device__ __forceinline__ AccCol acc_col(int n, float (&dummy)[11])
+    // One slot (or one overflow step): pixels n < KS - SA take side A's selection, the others side B's.
+    template <int SA>
+    __device__ __forceinline__ void slot_apply(const float (&w)[KS], const SlotSide &sa, const SlotSide &sb, int step)
     {
-        AccCol c;
+        float dl[KS], dg[KS], t[KS];
+        int pp[KS];
 #pragma unroll
-        for (int i = 0; i < 11; ++i) c.r[i] = i < CH ? &st.acc[i][n] : &dummy[i];
-        return c;
-    }
-    // pixels [N0, N1) of one side, two at a time
-    template <int N0, int N1>
-    __device__ __forceinline__ void correct_side(const float (&w)[KS], const SlotSide &sd, int step, float (&dummy)[11])
-    {
-        if constexpr (N1 - N0 >= 2) {
-            corr_pair<N0>(acc_col(N0, dummy), acc_col(N0 + 1, dummy), w[N0], w[N0 + 1], sd, step);
-            correct_side<N0 + 2, N1>(w, sd, step, dummy);
-        } else if constexpr (N1 - N0 == 1) {
-            corr_one<N0>(acc_col(N0, dummy), w[N0], sd, step);
+        for (int n = 0; n < KS; ++n) {
+            const bool a = n < KS - SA;
+            pp[n] = a ? sa.p : sb.p;
+            dl[n] = a ? sa.d_lt : sb.d_lt;
+            dg[n] = a ? sa.d_ge : sb.d_ge;
         }
+        uint32_t tmp;
+        MFL_CORR_SLOT();
+        (void)t;
+        (void)tmp;
     }
     __device__ __forceinline__ SlotSide slot_side(int mode, int T, float shared, float extra) const
     {
@@ -327,10 +300,8 @@ struct Loop {
     template <int SA>
     __device__ __forceinline__ void correct(uint32_t hdr, const float (&w)[KS])
     {
-        static_assert(CH <= 11, "the correction blocks name 11 step rows");
         const int nslots = (hdr >> 16) & 7;
         constexpr int sb = 2 * CH + 1;
-        float dummy[11] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < kDiagSlots; ++j) {
             // an empty slot keeps step = 15: its blocks exit at once
@@ -342,17 +313,16 @@ struct Loop {
                 sa = slot_side((desc >> 4) & 3, (int)((desc >> 8) & 127) - 64, v.FA[j], v.EA[j]);
                 if constexpr (SA > 0) sb_ = slot_side((desc >> 6) & 3, (int)((desc >> 16) & 127) - 64, v.FB[j], v.EB[j]);
             }
-            correct_side<0, KS - SA>(w, sa, step, dummy);
-            if constexpr (SA > 0) correct_side<KS - SA, KS>(w, sb_, step, dummy);
+            slot_apply<SA>(w, sa, sb_, step);
         }
-        if (hdr & 0x80000000u) overflow_loop<SA>(hdr, w, dummy);
+        if (hdr & 0x80000000u) overflow_loop<SA>(hdr, w);
     }
 
     // A record with more flagged steps than slots (narrow images): the steps past the slots are
     // walked in a wave-uniform loop.  Each one derives the slot description from the step's column
     // word, loads its four elements on demand and goes through the same correction blocks.
     template <int SA>
-    __device__ __forceinline__ void overflow_loop(uint32_t hdr, const float (&w)[KS], float (&dummy)[11])
+    __device__ __forceinline__ void overflow_loop(uint32_t hdr, const float (&w)[KS])
     {
         const int voff = lane * 4;
         uint32_t m = hdr & 0xffffu;
@@ -375,13 +345,13 @@ struct Loop {
             side(oA, xA, mA, tA, eA);
             const float FAv = buf_load(rsrc, voff, oA), EAv = buf_load(rsrc, voff, eA);
             const SlotSide sa = slot_side(mA, tA, FAv, EAv);
-            correct_side<0, KS - SA>(w, sa, i, dummy);
+            SlotSide sb_{0.f, 0.f, 0};
             if constexpr (SA > 0) {
                 side(oB, xB, mB, tB, eB);
                 const float FBv = buf_load(rsrc, voff, oB), EBv = buf_load(rsrc, voff, eB);
-                const SlotSide sb_ = slot_side(mB, tB, FBv, EBv);
-                correct_side<KS - SA, KS>(w, sb_, i, dummy);
+                sb_ = slot_side(mB, tB, FBv, EBv);
             }
+            slot_apply<SA>(w, sa, sb_, i);
         }
     }
 
@@ -454,13 +424,11 @@ struct Loop {
             // loads of one weight tap are issued before a gather tap and turned into weights after it,
             // so their latency hides behind the tap.
             using WP = WeightPhase<CH, KS, NGW, NCS>;
-            uint32_t gn = 0;
-            int nkyn = 0;
-            if (gidx + 1 < ngroups) {
-                gn = groups[gidx + 1];
-                nkyn = gn >> 24;
-                touch_records(gn);
-            }
+            // (the last group produces the first group's weights once more into the free buffer, so
+            // that every group runs the same branch-free loop)
+            const uint32_t gn = groups[gidx + 1 < ngroups ? gidx + 1 : 0];
+            const int nkyn = gn >> 24;
+            if (gidx + 1 < ngroups) touch_records(gn);
             const int kxn = (gn >> 8) & 255, ky0n = (gn >> 16) & 255;
             const int dxn = kxn - p0;
             float *wnext = lds + ((gidx + 1) & 1) * bufsz;
@@ -468,7 +436,21 @@ struct Loop {
             const int nky = gw >> 24;
             const int ntap = nky > nkyn ? nky : nkyn;
             MFL_STAMP(3 + 3 * gidx);
-            for (int tt = 0; tt < ntap; ++tt) {
+            // Steady state: a tap of this group between the image loads and the weight stores of a
+            // tap of the next group, with no branch in between (the wait counts before the stores then
+            // skip over the tap's element loads instead of draining them).
+            int tt = 0;
+#if !defined(MFL_ABL_NO_WEIGHT) && !defined(MFL_ABL_NO_GATHER)
+            const int ncommon = live ? (nky < nkyn ? nky : nkyn) : 0;
+            for (; tt < ncommon; ++tt) {
+                typename WP::Nb nb;
+                WP::load(nb, st, irsrc, (ky0n + tt) * Wp + kxn);
+                tap<SA>(wt + tt * Cfg::SLOTP);
+                const int dyn = ky0n + tt - p0;
+                WP::store(nb, st, (float)(dyn * dyn + dxn * dxn) * pw, cw, wnext + tt * Cfg::SLOTP);
+            }
+#endif
+            for (; tt < ntap; ++tt) {
                 typename WP::Nb nb;
 #ifndef MFL_ABL_NO_WEIGHT
                 if (tt < nkyn) WP::load(nb, st, irsrc, (ky0n + tt) * Wp + kxn);
