@@ -406,11 +406,12 @@ struct DiagWorkspace {
 };
 
 // dst[CE][CE] = src[C][C] zero-padded: constant row pitch for the fused epilogue's scalar loads
-__global__ void pad_compat_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int CE)
+// dst[c2][c] = src[c][c2], zero-padded to CE2 x CE2 (CE2 even): the layout the fused epilogue reads
+__global__ void pad_compat_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int CE2)
 {
-    for (int i = threadIdx.x; i < CE * CE; i += blockDim.x) {
-        const int r = i / CE, c = i - r * CE;
-        dst[i] = (r < C && c < C) ? src[r * C + c] : 0.f;
+    for (int i = threadIdx.x; i < CE2 * CE2; i += blockDim.x) {
+        const int c2 = i / CE2, c = i - c2 * CE2;
+        dst[i] = (c < C && c2 < C) ? src[c * C + c2] : 0.f;
     }
 }
 
@@ -426,7 +427,7 @@ DiagWorkspace diag_carve(int op, const DiagGeom &g)
     w.ip4 = take(((size_t)g.B * g.plane + 64) * sizeof(F4));
     w.table = take(diag_table_dwords(g) * 4);
     w.groups = take((size_t)g.k * g.k * 4);
-    w.compat = take((size_t)(g.CH * g.NCS) * (g.CH * g.NCS) * 4);
+    w.compat = take((size_t)(g.CH * g.NCS + 1) * (g.CH * g.NCS + 1) * 4);
     w.total = off;
     return w;
 }
@@ -471,7 +472,7 @@ void diag_lds(const DiagGeom &g, DiagArgs &a)
     const size_t wbytes = 2 * (size_t)g.TB * g.NBR * g.RUNP * 4;
     const size_t lds = wbytes > 96 * 1024 ? wbytes : 96 * 1024;
     // the epilogue passes the workgroup's b rows through LDS in equal chunks (fewest that fit)
-    const int max_rows = (int)(lds / ((size_t)g.C * g.RUNP * 4));
+    const int max_rows = (int)(lds / ((size_t)g.CH * g.NCS * g.RUNP * 4));
     const int chunks = (g.NBR + max_rows - 1) / max_rows;
     const int rows = (g.NBR + chunks - 1) / chunks;
     a.lds_bytes = lds;
@@ -655,7 +656,7 @@ int mfl_meanfield_forward(const float *unary, const float *img, const float *pos
         da.ab = affine_b;
         if (compat) {
             float *cpad = (float *)(base + ws.compat);
-            hipLaunchKernelGGL(pad_compat_kernel, dim3(1), dim3(kThreads), 0, st, compat, cpad, C, dg.CH * dg.NCS);
+            hipLaunchKernelGGL(pad_compat_kernel, dim3(1), dim3(kThreads), 0, st, compat, cpad, C, (dg.CH * dg.NCS + 1) & ~1);
             da.compat = cpad;
         }
         for (int it = 0; it < iters; ++it) {
