@@ -21,10 +21,6 @@
 #include "../../include/mfl.h"
 #include "mfl_diag_api.h"
 
-#ifndef MFL_EPI_P
-#define MFL_EPI_P 1   // pixels a thread of the fused epilogue works on at a time
-#endif
-
 #if !defined(MFL_DIAG_CH) || !defined(MFL_DIAG_KS)
 #error "compile with -DMFL_DIAG_CH=<channels per wave> -DMFL_DIAG_KS=<window side>"
 #endif
@@ -572,186 +568,191 @@ diag_kernel(DiagGeom g, int epi_rows, const float *__restrict__ xp, const F4 *__
 
     // ---- epilogue: accumulators -> LDS [channel][b_rel][a_rel], then one pixel per thread ----
     const int CBR = epi_rows;
-    for (int cb0 = 0; cb0 < Cfg::NBR; cb0 += CBR) {
-        // (the LDS tile has room for all CH * NCS channel rows, so the padded channels of the last
-        // split are written without a guard and never read)
+    const int cstride = CBR * Cfg::RUNP;
+    // pixel r of the chunk starting at b row cb0: LDS place, output pixel l and centre position in
+    // the padded plane; false for the places of the tile that are no pixel of this workgroup
+    auto place = [&](int cb0, int r, int &moff, int &l, int &cpos) {
+        const int rows = (Cfg::NBR - cb0 < CBR) ? Cfg::NBR - cb0 : CBR;
+        const int br = r / Cfg::RUN, a_rel = r - br * Cfg::RUN;
+        const int b_rel = cb0 + br;
+        const int n = a_rel % KS;
+        const int owner = b_rel - (KS - 1) + n;
+        const int aa = gb * Cfg::RUN + a_rel, bb = 64 * beta + b_rel - (KS - 1);
+        const long long l64 = (long long)aa + (long long)bb * CK;
+        const bool ok = br < rows && owner >= 0 && owner <= 63 && bb >= 0 && aa < CK && l64 < L;
+        l = ok ? (int)l64 : 0;
+        const int y = l / W, x = l - y * W;
+        cpos = (y + g.p0) * Wp + x + g.p0;
+        moff = ok ? br * Cfg::RUNP + a_rel : 0;
+        return ok;
+    };
+    // accumulators of the b rows [cb0, cb0 + CBR) -> LDS.  The tile has room for all CH * NCS channel
+    // rows, so the padded channels of the last split are written without a guard and never read.
+    auto transpose = [&](int cb0) {
         if (live) {
-            const int crow = CBR * Cfg::RUNP;
 #pragma unroll
             for (int n = 0; n < KS; ++n) {
                 const int br = lane - n + KS - 1 - cb0;
                 if (br >= 0 && br < CBR) {
                     float *dst = lds + (ci * CH * CBR + br) * Cfg::RUNP + gi * KS + n;
 #pragma unroll
-                    for (int i = 0; i < CH; ++i) dst[i * crow] = st.acc[i][n];
+                    for (int i = 0; i < CH; ++i) dst[i * cstride] = st.acc[i][n];
                 }
             }
         }
-        MFL_STAMP(42 + 4 * (cb0 != 0));
-        __syncthreads();
-        MFL_STAMP(43 + 4 * (cb0 != 0));
-        const int rows = (Cfg::NBR - cb0 < CBR) ? Cfg::NBR - cb0 : CBR;
-        const int cnt = rows * Cfg::RUN;
-        const int cstride = CBR * Cfg::RUNP;
-        // pixel r of the chunk: LDS place, output pixel l and centre position in the padded plane;
-        // false for the places of the tile that are no pixel of this workgroup
-        auto place = [&](int r, const float *&msg, int &l, int &cpos) {
-            const int br = r / Cfg::RUN, a_rel = r - br * Cfg::RUN;
-            const int b_rel = cb0 + br;
-            const int n = a_rel % KS;
-            const int owner = b_rel - (KS - 1) + n;
-            const int aa = gb * Cfg::RUN + a_rel, bb = 64 * beta + b_rel - (KS - 1);
-            const long long l64 = (long long)aa + (long long)bb * CK;
-            const bool ok = r < cnt && owner >= 0 && owner <= 63 && bb >= 0 && aa < CK && l64 < L;
-            l = ok ? (int)l64 : 0;
-            const int y = l / W, x = l - y * W;
-            cpos = (y + g.p0) * Wp + x + g.p0;
-            msg = lds + (ok ? br * Cfg::RUNP + a_rel : 0);
-            return ok;
-        };
-        if constexpr (MODE == 1) {
+    };
+    if constexpr (MODE == 1) {
+        for (int cb0 = 0; cb0 < Cfg::NBR; cb0 += CBR) {
+            transpose(cb0);
+            __syncthreads();
+            const int rows = (Cfg::NBR - cb0 < CBR) ? Cfg::NBR - cb0 : CBR;
+            const int cnt = rows * Cfg::RUN;
 #ifdef MFL_ABL_NO_EPI
             for (int r = tid; r < 1; r += Cfg::NT) {
 #else
             for (int r = tid; r < cnt; r += Cfg::NT) {
 #endif
-                const float *msg;
-                int l, cpos;
-                if (!place(r, msg, l, cpos)) continue;
+                int moff, l, cpos;
+                if (!place(cb0, r, moff, l, cpos)) continue;
+                const float *msg = lds + moff;
                 const float *qc = in_b + g.FS + cpos;
                 float *y_b = y_out + (size_t)img * C * L + l;
                 for (int c = 0; c < C; ++c) y_b[(size_t)c * L] = msg[c * cstride] * qc[(size_t)c * g.plane];
             }
-        } else {
-            // Two pixels per thread at a time: every row of the label matrix (wide scalar loads) then
-            // feeds both.  Channel planes are reached with scalar offsets (buffer addressing): no
-            // per-channel address arithmetic in the vector unit.  Channels past C read channel C-1
-            // and are neutralised by value (message 0, unary -inf), so that all loads issue back to back.
-            constexpr int CE = Cfg::CE, CE2 = (CE + 1) & ~1, P = MFL_EPI_P;
-            typedef float f2 __attribute__((ext_vector_type(2)));
-            const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)(in_b + g.FS), 0, 0x7fffffff, 0x00020000);
-            const __amdgpu_buffer_rsrc_t ru =
-                __builtin_amdgcn_make_buffer_rsrc((void *)(unary + (size_t)img * C * L), 0, 0x7fffffff, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rqo =
-                __builtin_amdgcn_make_buffer_rsrc((void *)(qp_out + img_off + g.FS), 0, 0x7fffffff, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rlq = __builtin_amdgcn_make_buffer_rsrc(
-                (void *)((logq ? logq : qp_out) + (size_t)img * C * L), 0, 0x7fffffff, 0x00020000);
-            const __amdgpu_buffer_rsrc_t raw = __builtin_amdgcn_make_buffer_rsrc((void *)(aw ? aw : unary), 0, 0x7fffffff, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rab = __builtin_amdgcn_make_buffer_rsrc((void *)(ab ? ab : unary), 0, 0x7fffffff, 0x00020000);
-            const int plane4 = g.plane * 4, L4 = L * 4;
-#ifdef MFL_ABL_NO_EPI
-            for (int r0 = tid; r0 < 1; r0 += P * Cfg::NT) {
-#else
-            for (int r0 = tid; r0 < cnt; r0 += P * Cfg::NT) {
-#endif
-                const float *msg[P];
-                int l[P], cpos[P];
-                bool ok[P];
+            __syncthreads();
+        }
+    } else {
+        // One pixel per thread and pass.  The pixel's unary and Q values do not depend on the gather,
+        // so the passes are software pipelined: the loads of the next pass (possibly of the next
+        // chunk) are issued before the arithmetic of the current one, the very first ones before
+        // the accumulators go to LDS.  Channel planes are reached with scalar offsets (buffer
+        // addressing): no per-channel address arithmetic in the vector unit.  Channels past C read
+        // channel C-1 and are neutralised by value (unary -inf; their messages are finite and meet
+        // zero columns of the padded label matrix), so that all loads issue back to back.
+        constexpr int CE = Cfg::CE, CE2 = (CE + 1) & ~1;
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)(in_b + g.FS), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ru =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(unary + (size_t)img * C * L), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rqo =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(qp_out + img_off + g.FS), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rlq = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)((logq ? logq : qp_out) + (size_t)img * C * L), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t raw = __builtin_amdgcn_make_buffer_rsrc((void *)(aw ? aw : unary), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rab = __builtin_amdgcn_make_buffer_rsrc((void *)(ab ? ab : unary), 0, 0x7fffffff, 0x00020000);
+        const int plane4 = g.plane * 4, L4 = L * 4;
+        struct Pixel {
+            bool ok;
+            int moff, l, cpos;
+            float u[CE], qv[CE];
+        };
+        auto fetch = [&](int cb0, int it, Pixel &x) {
+            x.ok = place(cb0, tid + it * Cfg::NT, x.moff, x.l, x.cpos);
 #pragma unroll
-                for (int p = 0; p < P; ++p) ok[p] = place(r0 + p * Cfg::NT, msg[p], l[p], cpos[p]);
-                // channel-outer loops: a channel's scalar offsets serve both pixels and die at once
-                float m[P][CE], u[P][CE], qv[P][CE];
+            for (int c = 0; c < CE; ++c) {
+                const int cc = c < C ? c : C - 1;
+                x.qv[c] = buf_load(rq, x.cpos * 4, (uint32_t)(cc * plane4));
+                x.u[c] = buf_load(ru, x.l * 4, (uint32_t)(cc * L4));
+            }
+        };
+        // (wide channel capacities have no registers to spare for a second set of loaded values)
+        constexpr bool kPrefetch = CE <= 24;
+        Pixel nxt;
+        if constexpr (kPrefetch) fetch(0, 0, nxt);
+        for (int cb0 = 0; cb0 < Cfg::NBR; cb0 += CBR) {
+            transpose(cb0);
+            MFL_STAMP(42 + 4 * (cb0 != 0));
+            __syncthreads();
+            MFL_STAMP(43 + 4 * (cb0 != 0));
+            const int rows = (Cfg::NBR - cb0 < CBR) ? Cfg::NBR - cb0 : CBR;
+#ifdef MFL_ABL_NO_EPI
+            const int nit = 0;
+#else
+            const int nit = (rows * Cfg::RUN + Cfg::NT - 1) / Cfg::NT;
+#endif
+            for (int it = 0; it < nit; ++it) {
+                Pixel cur;
+                if constexpr (kPrefetch) {
+                    cur = nxt;
+                    // the pass after this one (after the last one: this one again, loaded and dropped,
+                    // which keeps the loop free of branches around loads)
+                    const bool more = it + 1 < nit, chunk = cb0 + CBR < Cfg::NBR;
+                    fetch(more ? cb0 : (chunk ? cb0 + CBR : cb0), more ? it + 1 : (chunk ? 0 : it), nxt);
+                } else {
+                    fetch(cb0, it, cur);
+                }
+                const float *msg = lds + cur.moff;
+                const int l = cur.l, cpos = cur.cpos;
+                float m[CE], u[CE];
 #pragma unroll
                 for (int c = 0; c < CE; ++c) {
                     const int cc = c < C ? c : C - 1;
-#pragma unroll
-                    for (int p = 0; p < P; ++p) {
-                        m[p][c] = msg[p][cc * cstride];
-                        qv[p][c] = buf_load(rq, cpos[p] * 4, (uint32_t)(cc * plane4));
-                        u[p][c] = buf_load(ru, l[p] * 4, (uint32_t)(cc * L4));
-                    }
+                    m[c] = msg[cc * cstride];
+                    u[c] = cur.u[c];
                 }
                 if (aw) {
 #pragma unroll
                     for (int c = 0; c < CE; ++c) {
                         const int cc = c < C ? c : C - 1;
-#pragma unroll
-                        for (int p = 0; p < P; ++p) {
-                            const float av = buf_load(raw, l[p] * 4, (uint32_t)(cc * L4));
-                            const float bv = buf_load(rab, l[p] * 4, (uint32_t)(cc * L4));
-                            m[p][c] = fmaf(av, m[p][c] * qv[p][c], bv);
-                        }
+                        const float av = buf_load(raw, l * 4, (uint32_t)(cc * L4));
+                        const float bv = buf_load(rab, l * 4, (uint32_t)(cc * L4));
+                        m[c] = fmaf(av, m[c] * cur.qv[c], bv);
                     }
                 } else {
 #pragma unroll
-                    for (int c = 0; c < CE; ++c)
-#pragma unroll
-                        for (int p = 0; p < P; ++p) m[p][c] *= qv[p][c];
+                    for (int c = 0; c < CE; ++c) m[c] *= cur.qv[c];
                 }
-                float lse_u[P];
+                float mu = -INFINITY;
 #pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    float mu = -INFINITY;
-#pragma unroll
-                    for (int c = 0; c < CE; ++c) {
-                        // (channel splits leave at most 7 padded channels: only those need the test;
-                        // their messages are finite and meet zero columns of the padded label matrix)
-                        if (c >= CE - 7) u[p][c] = c < C ? u[p][c] : -INFINITY;
-                        mu = fmaxf(mu, u[p][c]);
-                    }
-                    float su = 0.f;
-#pragma unroll
-                    for (int c = 0; c < CE; ++c) su += __expf(u[p][c] - mu);
-                    lse_u[p] = mu + __logf(su);
+                for (int c = 0; c < CE; ++c) {
+                    // (channel splits leave at most 7 padded channels: only those need the test)
+                    if (c >= CE - 7) u[c] = c < C ? u[c] : -INFINITY;
+                    mu = fmaxf(mu, u[c]);
                 }
+                float su = 0.f;
+#pragma unroll
+                for (int c = 0; c < CE; ++c) su += __expf(u[c] - mu);
+                const float lse_u = mu + __logf(su);
                 // compat: the transposed, zero-padded CE2 x CE2 copy of the C x C matrix, so that a
                 // pair of output channels is one packed FMA with a scalar register pair
-                f2 pv[P][CE2 / 2];
+                f2 pv[CE2 / 2];
                 if (compat) {
                     const f2 *ct = reinterpret_cast<const f2 *>(compat);
 #pragma unroll
-                    for (int p = 0; p < P; ++p)
-#pragma unroll
-                        for (int cp = 0; cp < CE2 / 2; ++cp) pv[p][cp] = f2{0.f, 0.f};
+                    for (int cp = 0; cp < CE2 / 2; ++cp) pv[cp] = f2{0.f, 0.f};
 #pragma unroll
                     for (int c2 = 0; c2 < CE; ++c2)
 #pragma unroll
-                        for (int cp = 0; cp < CE2 / 2; ++cp) {
-                            const f2 cv = ct[c2 * (CE2 / 2) + cp];
-#pragma unroll
-                            for (int p = 0; p < P; ++p)
-                                pv[p][cp] = __builtin_elementwise_fma(cv, f2{m[p][c2], m[p][c2]}, pv[p][cp]);
-                        }
+                        for (int cp = 0; cp < CE2 / 2; ++cp)
+                            pv[cp] = __builtin_elementwise_fma(ct[c2 * (CE2 / 2) + cp], f2{m[c2], m[c2]}, pv[cp]);
                 } else {
 #pragma unroll
-                    for (int p = 0; p < P; ++p)
-#pragma unroll
-                        for (int cp = 0; cp < CE2 / 2; ++cp)
-                            pv[p][cp] = f2{m[p][2 * cp], 2 * cp + 1 < CE ? m[p][2 * cp + 1] : 0.f};
+                    for (int cp = 0; cp < CE2 / 2; ++cp) pv[cp] = f2{m[2 * cp], 2 * cp + 1 < CE ? m[2 * cp + 1] : 0.f};
                 }
-                float lse_v[P];
+                float mv = -INFINITY;
 #pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    float mv = -INFINITY;
-#pragma unroll
-                    for (int c = 0; c < CE; ++c) {
-                        u[p][c] = (u[p][c] - lse_u[p]) - pv[p][c / 2][c & 1];
-                        mv = fmaxf(mv, u[p][c]);
-                    }
-                    float sv = 0.f;
-#pragma unroll
-                    for (int c = 0; c < CE; ++c) sv += __expf(u[p][c] - mv);
-                    lse_v[p] = mv + __logf(sv);
+                for (int c = 0; c < CE; ++c) {
+                    u[c] = (u[c] - lse_u) - pv[c / 2][c & 1];
+                    mv = fmaxf(mv, u[c]);
                 }
+                float sv = 0.f;
 #pragma unroll
-                for (int c = 0; c < CE; ++c)
-                    if (c < C) {
+                for (int c = 0; c < CE; ++c) sv += __expf(u[c] - mv);
+                const float lse_v = mv + __logf(sv);
+                if (cur.ok) {
 #pragma unroll
-                        for (int p = 0; p < P; ++p) {
-                            const float lq = u[p][c] - lse_v[p];
-                            if (ok[p]) {
-                                if (logq)
-                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, lq), rlq, l[p] * 4, c * L4, 0);
-                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, __expf(lq)), rqo, cpos[p] * 4,
-                                                                      c * plane4, 0);
-                            }
+                    for (int c = 0; c < CE; ++c)
+                        if (c < C) {
+                            const float lq = u[c] - lse_v;
+                            if (logq) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, lq), rlq, l * 4, c * L4, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, __expf(lq)), rqo, cpos * 4, c * plane4, 0);
                         }
-                    }
+                }
             }
+            MFL_STAMP(44 + 4 * (cb0 != 0));
+            __syncthreads();
+            MFL_STAMP(45 + 4 * (cb0 != 0));
         }
-        MFL_STAMP(44 + 4 * (cb0 != 0));
-        __syncthreads();
-        MFL_STAMP(45 + 4 * (cb0 != 0));
     }
     MFL_STAMP(41);
 }
