@@ -735,18 +735,29 @@ diag_kernel(DiagGeom g, int epi_rows, const float *__restrict__ xp, const F4 *__
                     u[c] = (u[c] - lse_u) - pv[c / 2][c & 1];
                     mv = fmaxf(mv, u[c]);
                 }
+                // Q_{t+1} = exp(u - mv) / sum: the exponentials of the sum are reused for the output
                 float sv = 0.f;
 #pragma unroll
-                for (int c = 0; c < CE; ++c) sv += __expf(u[c] - mv);
-                const float lse_v = mv + __logf(sv);
+                for (int c = 0; c < CE; ++c) {
+                    u[c] -= mv;
+                    m[c] = __expf(u[c]);
+                    sv += m[c];
+                }
+                const float rsv = 1.f / sv;
+#ifdef MFL_ABL_EPI_NOSTORE
+                if (cur.ok && rsv == 1234.5f) {
+#else
                 if (cur.ok) {
+#endif
 #pragma unroll
                     for (int c = 0; c < CE; ++c)
-                        if (c < C) {
-                            const float lq = u[c] - lse_v;
-                            if (logq) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, lq), rlq, l * 4, c * L4, 0);
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, __expf(lq)), rqo, cpos * 4, c * plane4, 0);
-                        }
+                        if (c < C) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, m[c] * rsv), rqo, cpos * 4, c * plane4, 0);
+                    if (logq) {
+                        const float lsv = __logf(sv);
+#pragma unroll
+                        for (int c = 0; c < CE; ++c)
+                            if (c < C) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, u[c] - lsv), rlq, l * 4, c * L4, 0);
+                    }
                 }
             }
             MFL_STAMP(44 + 4 * (cb0 != 0));
