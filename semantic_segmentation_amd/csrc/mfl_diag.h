@@ -95,19 +95,18 @@ inline bool diag_supported(int C, int H, int W, int k)
 //   [CH, 2CH)            byte offsets of B
 //   [2CH]                header: bit i (i < CH) step i is flagged; bits 16..18 number of slots;
 //                        bit 31 more flagged steps than slots (the per-step columns below are needed)
-//   [2CH+1, +5*slots)    slots, one per flagged step (at most kDiagSlots), 5 dwords each:
-//                          descriptor  step | modeA << 4 | modeB << 6 | (TA + 64) << 8 | (TB + 64) << 16
-//                          byte offsets of the extra and of the shared element of side A, then of side B
-//                        mode 0: side not affected; 1: the run wraps to the next image row at lane T
-//                        (extra element = gap floats further); 2: the row started -T <= k-2 pixels
-//                        before lane 0 (extra element = gap floats earlier).  With p = lane - T and
-//                        D = extra - shared element, pixel n of the side adds D if (mode 1) p >= n or
-//                        (mode 2) p < n.
-//   [xw base, ...)       16-bit pairs: xA | (xB != xA) << 15
+//   [2CH+1, +slots)      slots, one dword per flagged step (at most kDiagSlots):
+//                          step | (TA + 64) << 8 | (TB + 64) << 16
+//   [xw base, ...)       16-bit pairs: xA | (xB != xA) << 15   (lane-0 source columns, for the steps
+//                        past the slots)
+// A flagged side is described by a threshold T (diag_side): with p = lane - T, pixel n of the lane
+// reads the table's element ("shared") if p < n and the element gap floats further ("extra") if
+// p >= n.  Where the run wraps to the next image row at lane T (1 <= T <= 63) the table holds the
+// plain offset; where the row started -T <= k-2 pixels before lane 0 it holds the offset moved back
+// by the gap, so that one rule serves both; a side that meets no row start has T = 64 (p < 0 <= n).
 constexpr int kDiagSlots = 3;
-constexpr int kDiagSlotWords = 5;
 MFL_HD int diag_slot_base(int CH) { return 2 * CH + 1; }
-MFL_HD int diag_xw_base(int CH) { return 2 * CH + 1 + kDiagSlotWords * kDiagSlots; }
+MFL_HD int diag_xw_base(int CH) { return 2 * CH + 1 + kDiagSlots; }
 MFL_HD int diag_recw(int CH) { return ((diag_xw_base(CH) + (CH + 1) / 2 + 3) / 4) * 4; }
 
 // Returns 0 on success, -1 invalid, -3 too large for 32-bit indexing.
@@ -217,12 +216,13 @@ MFL_HD int diag_groups(const DiagGeom &g, uint32_t *out)
     return n;
 }
 
-// Side of a flagged step: mode, threshold lane and offset of the extra element (see diag_recw).
-MFL_HD void diag_side(const DiagGeom &g, int off, int x0, int &mode, int &T, int &offE)
+// One side of a step whose lane-0 element has float index `off` and source column x0: the threshold
+// T and the float index the table holds (see the record layout above).
+MFL_HD void diag_side(const DiagGeom &g, int off, int x0, int &T, int &off_table)
 {
-    if (x0 + 63 > g.W - 1) { mode = 1; T = g.W - x0; offE = off + g.gap; }
-    else if (x0 < g.k - 1) { mode = 2; T = -x0; offE = off - g.gap; }
-    else { mode = 0; T = 0; offE = off; }
+    if (x0 + 63 > g.W - 1) { T = g.W - x0; off_table = off; }
+    else if (x0 < g.k - 1) { T = -x0; off_table = off - g.gap; }
+    else { T = 64; off_table = off; }
 }
 
 // Fill one table record (all CH steps of one (beta, gamma, t, channel split)); layout: diag_recw.
@@ -237,43 +237,25 @@ MFL_HD void diag_fill_record(const DiagGeom &g, int beta, int gamma, int t, int 
         const bool dummy = c >= g.C;
         if (dummy) c = ci * g.CH < g.C ? ci * g.CH : 0;
         const DiagStep st = diag_step(g, beta, gamma, t, c);
-        rec[i] = (uint32_t)st.offA * 4u;
-        rec[g.CH + i] = (uint32_t)st.offB * 4u;
+        int tA, tB, oA, oB;
+        diag_side(g, st.offA, st.xA, tA, oA);
+        diag_side(g, st.offB, st.xB, tB, oB);
+        rec[i] = (uint32_t)oA * 4u;
+        rec[g.CH + i] = (uint32_t)oB * 4u;
         const uint32_t x16 = (uint32_t)st.xA | ((st.xB != st.xA) ? 0x8000u : 0u);
         rec[xb + i / 2] |= x16 << (16 * (i & 1));
         if (st.flagged && !dummy) {
             flags |= 1u << i;
             ++nflagged;
-            if (nslots < kDiagSlots) {
-                int mA, tA, eA, mB, tB, eB;
-                diag_side(g, st.offA, st.xA, mA, tA, eA);
-                diag_side(g, st.offB, st.xB, mB, tB, eB);
-                uint32_t *slot = rec + sb + kDiagSlotWords * nslots;
-                slot[0] = (uint32_t)i | ((uint32_t)mA << 4) | ((uint32_t)mB << 6) | ((uint32_t)(tA + 64) << 8) |
-                          ((uint32_t)(tB + 64) << 16);
-                slot[1] = (uint32_t)eA * 4u;
-                slot[2] = (uint32_t)st.offA * 4u;
-                slot[3] = (uint32_t)eB * 4u;
-                slot[4] = (uint32_t)st.offB * 4u;
-                ++nslots;
-            }
+            if (nslots < kDiagSlots)
+                rec[sb + nslots++] = (uint32_t)i | ((uint32_t)(tA + 64) << 8) | ((uint32_t)(tB + 64) << 16);
         }
-    }
-    // unused slots point at valid elements
-    for (int j = nslots; j < kDiagSlots; ++j) {
-        uint32_t *slot = rec + sb + kDiagSlotWords * j;
-        slot[1] = slot[2] = rec[0];
-        slot[3] = slot[4] = rec[g.CH];
     }
     rec[2 * g.CH] = flags | ((uint32_t)nslots << 16) | (nflagged > kDiagSlots ? 0x80000000u : 0u);
 }
 
-// What pixel n of lane `lane` adds to the shared element for one side of a slot (D = extra - shared).
-MFL_HD bool diag_slot_selects(int mode, int T, int lane, int n)
-{
-    const int p = lane - T;
-    return mode == 1 ? p >= n : (mode == 2 ? p < n : false);
-}
+// Whether pixel n of lane `lane` reads the extra element of a side with threshold T.
+MFL_HD bool diag_reads_extra(int T, int lane, int n) { return lane - T >= n; }
 
 }  // namespace mfl
 

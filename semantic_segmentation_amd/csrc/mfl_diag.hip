@@ -132,8 +132,8 @@ struct WeightPhase {
 template <int CH>
 struct TapVals {
     float A[CH], B[CH];
-    // per slot: extra and shared element of side A, of side B (slots: steps that meet an image-row start)
-    float EA[kDiagSlots], FA[kDiagSlots], EB[kDiagSlots], FB[kDiagSlots];
+    // per slot (a step that meets an image-row start): the extra element of side A, of side B
+    float EA[kDiagSlots], EB[kDiagSlots];
 };
 
 __device__ __forceinline__ uint32_t rec_word(uint32_t recv, int j)
@@ -142,21 +142,16 @@ __device__ __forceinline__ uint32_t rec_word(uint32_t recv, int j)
 }
 
 // ---- corrections of flagged steps -------------------------------------------------------------
-// One side (A or B) of a slot: with p = lane - T and D = extra - shared element, pixel n of the side
-// adds w[n] * D if (mode 1: the run wraps to the next image row at lane T) p >= n, or (mode 2: the
-// row started -T pixels before lane 0) p < n.  SlotSide carries d_ge / d_lt = what p >= n / p < n add.
-struct SlotSide {
-    float d_ge, d_lt;
-    int p;
-};
-
+// A flagged side has a threshold T (record layout: mfl_diag.h): with p = lane - T, pixel n of the lane
+// must read the "extra" element (gap floats after the table's "shared" one) if p >= n.  The taps
+// accumulate w[n] * shared for every pixel; the correction adds w[n] * (extra - shared) where p >= n.
 // The step a slot corrects is known at run time only, but the accumulators must be reached through
 // constant register names.  A C++ branch per step around accumulator updates makes the compiler copy
 // the accumulators on every path, so the whole decision sits inside ONE asm statement per slot: an
-// immediate exit for an empty slot (step >= CH), the per-pixel selection of what to add
-// (t[n] = p[n] >= n ? d_ge[n] : d_lt[n]), then a computed jump (s_getpc + step * body size) into a
-// table of per-step bodies, each k in-place v_fmac on the accumulators of that step and a branch out.
-// The bodies must keep the fixed size MFL_CORR_STRIDE = 4*k + 4 bytes (k 4-byte VOP2 + s_branch).
+// the per-pixel selection of the weight (t[n] = p[n] >= n ? w[n] : 0), then a computed jump
+// (s_getpc + step * body size) into a table of per-step bodies, each k times (v_sub: extra - shared
+// element of that step, in-place v_fmac on its accumulator) and a branch out.  The bodies must
+// keep the fixed size MFL_CORR_STRIDE = 8*k + 4 bytes (2k 4-byte VOP2 + s_branch).
 #if MFL_DIAG_CH == 5
 #define MFL_CORR_LIST(M) M(0) M(1) M(2) M(3) M(4)
 #define MFL_CORR_CH "5"
@@ -174,41 +169,56 @@ struct SlotSide {
 #endif
 #if MFL_DIAG_KS == 3
 #define MFL_KS_LIST(M, I) M(I, 0) M(I, 1) M(I, 2)
-#define MFL_CORR_STRIDE "16"
+#define MFL_CORR_STRIDE "28"
+#define MFL_CORR_SELS MFL_CORR_SEL2(0, 1) MFL_CORR_SEL1(2)
 #elif MFL_DIAG_KS == 5
 #define MFL_KS_LIST(M, I) M(I, 0) M(I, 1) M(I, 2) M(I, 3) M(I, 4)
-#define MFL_CORR_STRIDE "24"
+#define MFL_CORR_STRIDE "44"
+#define MFL_CORR_SELS MFL_CORR_SEL2(0, 1) MFL_CORR_SEL2(2, 3) MFL_CORR_SEL1(4)
 #elif MFL_DIAG_KS == 7
 #define MFL_KS_LIST(M, I) M(I, 0) M(I, 1) M(I, 2) M(I, 3) M(I, 4) M(I, 5) M(I, 6)
-#define MFL_CORR_STRIDE "32"
+#define MFL_CORR_STRIDE "60"
+#define MFL_CORR_SELS MFL_CORR_SEL2(0, 1) MFL_CORR_SEL2(2, 3) MFL_CORR_SEL2(4, 5) MFL_CORR_SEL1(6)
 #elif MFL_DIAG_KS == 9
 #define MFL_KS_LIST(M, I) M(I, 0) M(I, 1) M(I, 2) M(I, 3) M(I, 4) M(I, 5) M(I, 6) M(I, 7) M(I, 8)
-#define MFL_CORR_STRIDE "40"
+#define MFL_CORR_STRIDE "76"
+#define MFL_CORR_SELS MFL_CORR_SEL2(0, 1) MFL_CORR_SEL2(2, 3) MFL_CORR_SEL2(4, 5) MFL_CORR_SEL2(6, 7) MFL_CORR_SEL1(8)
 #elif MFL_DIAG_KS == 11
 #define MFL_KS_LIST(M, I) M(I, 0) M(I, 1) M(I, 2) M(I, 3) M(I, 4) M(I, 5) M(I, 6) M(I, 7) M(I, 8) M(I, 9) M(I, 10)
-#define MFL_CORR_STRIDE "48"
+#define MFL_CORR_STRIDE "92"
+#define MFL_CORR_SELS MFL_CORR_SEL2(0, 1) MFL_CORR_SEL2(2, 3) MFL_CORR_SEL2(4, 5) MFL_CORR_SEL2(6, 7) MFL_CORR_SEL2(8, 9) MFL_CORR_SEL1(10)
 #else
 #error "no pixel list for this MFL_DIAG_KS"
 #endif
-#define MFL_CORR_SEL(I, N) \
-    "v_cmp_le_i32 vcc, " #N ", %[p" #N "]\n\tv_cndmask_b32 %[t" #N "], %[dl" #N "], %[dg" #N "], vcc\n\t"
-#define MFL_CORR_FMA(I, N) "v_fmac_f32_e32 %[a" #I "_" #N "], %[w" #N "], %[t" #N "]\n\t"
+// common part: t[N] = (p[N] >= N) ? w[N] : 0 with p = lane - T of the pixel's side.  A VALU that
+// reads a scalar register (VCC included) written by a VALU needs two wait states in between on
+// gfx950, and nothing checks inline asm for that: two compares (into VCC and s[98:99]) and one
+// s_nop precede the two selects, the last pixel waits with s_nop 1.
+#define MFL_CORR_SEL2(N0, N1)                                                                      \
+    "v_cmp_le_i32 vcc, " #N0 ", %[p" #N0 "]\n\tv_cmp_le_i32 s[98:99], " #N1 ", %[p" #N1 "]\n\ts_nop 0\n\t" \
+    "v_cndmask_b32 %[t" #N0 "], 0, %[w" #N0 "], vcc\n\tv_cndmask_b32 %[t" #N1 "], 0, %[w" #N1 "], s[98:99]\n\t"
+#define MFL_CORR_SEL1(N) \
+    "v_cmp_le_i32 vcc, " #N ", %[p" #N "]\n\ts_nop 1\n\tv_cndmask_b32 %[t" #N "], 0, %[w" #N "], vcc\n\t"
+// body of step I, pixel N: acc += t * (extra element of the pixel's side - its shared element of step I)
+#define MFL_CORR_FMA(I, N) \
+    "v_sub_f32_e32 %[d], %[e" #N "], %[x" #I "_" #N "]\n\tv_fmac_f32_e32 %[a" #I "_" #N "], %[t" #N "], %[d]\n\t"
 #define MFL_CORR_BODY(I) MFL_KS_LIST(MFL_CORR_FMA, I) "s_branch 9f\n\t"
 #define MFL_CORR_ACC(I, N) [a##I##_##N] "+v"(st.acc[I][N]),
 #define MFL_CORR_ACCS(I) MFL_KS_LIST(MFL_CORR_ACC, I)
 #define MFL_CORR_TMP(I, N) [t##N] "=&v"(t[N]),
-#define MFL_CORR_IN(I, N) [w##N] "v"(w[N]), [p##N] "v"(pp[N]), [dl##N] "v"(dl[N]), [dg##N] "v"(dg[N]),
+#define MFL_CORR_IN(I, N) [w##N] "v"(w[N]), [p##N] "v"(N < NA ? pA : pB), [e##N] "v"(N < NA ? eA : eB),
+#define MFL_CORR_X(I, N) [x##I##_##N] "v"(N < NA ? v.A[I] : v.B[I]),
+#define MFL_CORR_XS(I) MFL_KS_LIST(MFL_CORR_X, I)
 // s[96:97] hold the jump target: named registers because the two halves are added separately
 #define MFL_CORR_SLOT()                                                                                   \
-    asm volatile("s_cmp_ge_u32 %[st], " MFL_CORR_CH "\n\ts_cbranch_scc1 9f\n\t"                          \
-                 MFL_KS_LIST(MFL_CORR_SEL, 0)                                                             \
+    asm volatile(MFL_CORR_SELS                                                                            \
                  "s_mul_i32 %[tmp], %[st], " MFL_CORR_STRIDE "\n\ts_add_u32 %[tmp], %[tmp], 12\n\t"      \
                  "s_getpc_b64 s[96:97]\n\ts_add_u32 s96, s96, %[tmp]\n\ts_addc_u32 s97, s97, 0\n\t"     \
                  "s_setpc_b64 s[96:97]\n\t"                                                               \
                  MFL_CORR_LIST(MFL_CORR_BODY) "9:"                                                        \
-                 : MFL_CORR_LIST(MFL_CORR_ACCS) MFL_KS_LIST(MFL_CORR_TMP, 0)[tmp] "=&s"(tmp)              \
-                 : MFL_KS_LIST(MFL_CORR_IN, 0)[st] "s"(step)                                              \
-                 : "vcc", "scc", "s96", "s97")
+                 : MFL_CORR_LIST(MFL_CORR_ACCS) MFL_KS_LIST(MFL_CORR_TMP, 0)[d] "=&v"(d), [tmp] "=&s"(tmp) \
+                 : MFL_KS_LIST(MFL_CORR_IN, 0) MFL_CORR_LIST(MFL_CORR_XS)[st] "s"(step)                   \
+                 : "vcc", "scc", "s96", "s97", "s98", "s99")
 
 template <int CH, int KS, int NGW, int NCS>
 struct Loop {
@@ -253,50 +263,38 @@ struct Loop {
         return ptr[lane < recw ? lane : 0];
     }
 
+    // Extra elements of the record's slots (steps known at run time: dynamic lane of the record).
     __device__ __forceinline__ void load_slots(uint32_t recv)
     {
         const int voff = lane * 4;
         constexpr int sb = 2 * CH + 1;
+        const int nslots = (rec_word(recv, 2 * CH) >> 16) & 7;
 #pragma unroll
         for (int j = 0; j < kDiagSlots; ++j) {
-            v.EA[j] = buf_load(rsrc, voff, rec_word(recv, sb + kDiagSlotWords * j + 1));
-            v.FA[j] = buf_load(rsrc, voff, rec_word(recv, sb + kDiagSlotWords * j + 2));
-            v.EB[j] = buf_load(rsrc, voff, rec_word(recv, sb + kDiagSlotWords * j + 3));
-            v.FB[j] = buf_load(rsrc, voff, rec_word(recv, sb + kDiagSlotWords * j + 4));
+            if (j < nslots) {
+                const int step = rec_word(recv, sb + j) & 15;
+                v.EA[j] = buf_load(rsrc, voff, rec_word(recv, step) + (uint32_t)gap4);
+                v.EB[j] = buf_load(rsrc, voff, rec_word(recv, CH + step) + (uint32_t)gap4);
+            }
         }
     }
 
-    // One slot (or one overflow step): pixels n < KS - SA take side A's selection, the others side B's.
+    // One slot (or one step past the slots): pixels n < KS - SA belong to side A, the others to side B.
     template <int SA>
-    __device__ __forceinline__ void slot_apply(const float (&w)[KS], const SlotSide &sa, const SlotSide &sb, int step)
+    __device__ __forceinline__ void slot_apply(const float (&w)[KS], int pA, int pB, float eA, float eB, int step)
     {
-        float dl[KS], dg[KS], t[KS];
-        int pp[KS];
-#pragma unroll
-        for (int n = 0; n < KS; ++n) {
-            const bool a = n < KS - SA;
-            pp[n] = a ? sa.p : sb.p;
-            dl[n] = a ? sa.d_lt : sb.d_lt;
-            dg[n] = a ? sa.d_ge : sb.d_ge;
-        }
+        constexpr int NA = KS - SA;
+        float t[KS], d;
         uint32_t tmp;
         MFL_CORR_SLOT();
         (void)t;
+        (void)d;
         (void)tmp;
-    }
-    __device__ __forceinline__ SlotSide slot_side(int mode, int T, float shared, float extra) const
-    {
-        const float D = extra - shared;
-        SlotSide sd;
-        sd.d_ge = mode == 1 ? D : 0.f;
-        sd.d_lt = mode == 2 ? D : 0.f;
-        sd.p = lane - T;
-        return sd;
     }
 
     // Steps of the accumulated tap that meet an image-row start: corrected in place from the slots'
-    // elements; a record with more flagged steps than slots (narrow images) takes the per-step path
-    // with loads on demand.
+    // elements; a record with more flagged steps than slots (narrow images) walks the others with
+    // loads on demand.
     template <int SA>
     __device__ __forceinline__ void correct(uint32_t hdr, const float (&w)[KS])
     {
@@ -304,23 +302,17 @@ struct Loop {
         constexpr int sb = 2 * CH + 1;
 #pragma unroll
         for (int j = 0; j < kDiagSlots; ++j) {
-            // an empty slot keeps step = 15: its blocks exit at once
-            int step = 15;
-            SlotSide sa{0.f, 0.f, 0}, sb_{0.f, 0.f, 0};
             if (j < nslots) {
-                const uint32_t desc = rec_word(rec_use, sb + kDiagSlotWords * j);
-                step = desc & 15;
-                sa = slot_side((desc >> 4) & 3, (int)((desc >> 8) & 127) - 64, v.FA[j], v.EA[j]);
-                if constexpr (SA > 0) sb_ = slot_side((desc >> 6) & 3, (int)((desc >> 16) & 127) - 64, v.FB[j], v.EB[j]);
+                const uint32_t desc = rec_word(rec_use, sb + j);
+                const int pA = lane - ((int)((desc >> 8) & 255) - 64), pB = lane - ((int)((desc >> 16) & 255) - 64);
+                slot_apply<SA>(w, pA, pB, v.EA[j], SA > 0 ? v.EB[j] : 0.f, desc & 15);
             }
-            slot_apply<SA>(w, sa, sb_, step);
         }
         if (hdr & 0x80000000u) overflow_loop<SA>(hdr, w);
     }
 
-    // A record with more flagged steps than slots (narrow images): the steps past the slots are
-    // walked in a wave-uniform loop.  Each one derives the slot description from the step's column
-    // word, loads its four elements on demand and goes through the same correction blocks.
+    // The steps past the slots, in a wave-uniform loop: each derives its thresholds from the step's
+    // column word, loads its extra elements on demand and goes through the same correction block.
     template <int SA>
     __device__ __forceinline__ void overflow_loop(uint32_t hdr, const float (&w)[KS])
     {
@@ -334,24 +326,11 @@ struct Loop {
             const uint32_t x16 = (rec_word(rec_use, diag_xw_base(CH) + (i >> 1)) >> (16 * (i & 1))) & 0xffffu;
             const int xA = x16 & 0x7fff;
             const int xB = (x16 & 0x8000) ? (xA + 1 == W ? 0 : xA + 1) : xA;
-            const uint32_t oA = rec_word(rec_use, i), oB = rec_word(rec_use, CH + i);
-            auto side = [&](uint32_t off, int x0, int &mode, int &T, uint32_t &offE) {
-                if (x0 + 63 > W - 1) { mode = 1; T = W - x0; offE = off + (uint32_t)gap4; }
-                else if (x0 < KS - 1) { mode = 2; T = -x0; offE = off - (uint32_t)gap4; }
-                else { mode = 0; T = 0; offE = off; }
-            };
-            int mA, tA, mB = 0, tB = 0;
-            uint32_t eA, eB = oB;
-            side(oA, xA, mA, tA, eA);
-            const float FAv = buf_load(rsrc, voff, oA), EAv = buf_load(rsrc, voff, eA);
-            const SlotSide sa = slot_side(mA, tA, FAv, EAv);
-            SlotSide sb_{0.f, 0.f, 0};
-            if constexpr (SA > 0) {
-                side(oB, xB, mB, tB, eB);
-                const float FBv = buf_load(rsrc, voff, oB), EBv = buf_load(rsrc, voff, eB);
-                sb_ = slot_side(mB, tB, FBv, EBv);
-            }
-            slot_apply<SA>(w, sa, sb_, i);
+            auto threshold = [&](int x0) { return x0 + 63 > W - 1 ? W - x0 : (x0 < KS - 1 ? -x0 : 64); };
+            const float eA = buf_load(rsrc, voff, rec_word(rec_use, i) + (uint32_t)gap4);
+            float eB = 0.f;
+            if constexpr (SA > 0) eB = buf_load(rsrc, voff, rec_word(rec_use, CH + i) + (uint32_t)gap4);
+            slot_apply<SA>(w, lane - threshold(xA), lane - threshold(xB), eA, eB, i);
         }
     }
 

@@ -69,33 +69,32 @@ extern "C" int emu_diag_local_forward(const float *x, const float *img, float pw
                                         const int off = (int)(rec[useA ? i : g.CH + i] / 4);
                                         int idx = off + lane;
                                         if (flagged) {
-                                            // a slot holds the step: the shared element plus, where
-                                            // selected, the difference to the slot's extra element;
-                                            // steps past the slots (overflow records): per-lane rule
+                                            // threshold of the side: from the step's slot, or (steps past
+                                            // the slots of an overflow record) from its column word as the
+                                            // device derives it
                                             const int nslots = (hdr >> 16) & 7;
-                                            const uint32_t *slot = nullptr;
-                                            for (int j = 0; j < nslots; ++j)
-                                                if ((int)(rec[diag_slot_base(g.CH) + kDiagSlotWords * j] & 15) == i)
-                                                    slot = rec + diag_slot_base(g.CH) + kDiagSlotWords * j;
-                                            if (!slot && !(hdr & 0x80000000u)) return -11;
-                                            if (slot) {
-                                                const int mode = useA ? (slot[0] >> 4) & 3 : (slot[0] >> 6) & 3;
-                                                const int T = (int)((slot[0] >> (useA ? 8 : 16)) & 127) - 64;
-                                                if ((int)(slot[useA ? 2 : 4] / 4) != off) return -12;
-                                                if (diag_slot_selects(mode, T, lane, n))
-                                                    idx = (int)(slot[useA ? 1 : 3] / 4) + lane;
-                                            } else {
-                                                const uint32_t x16 =
-                                                    (rec[diag_xw_base(g.CH) + i / 2] >> (16 * (i & 1))) & 0xffff;
-                                                const int xA = x16 & 0x7fff;
-                                                int xB = xA;
-                                                if (x16 & 0x8000) xB = (xA + 1 == W) ? 0 : xA + 1;
-                                                // the device derives the side description from the column word
-                                                int mode, T, offE;
-                                                diag_side(g, off, useA ? xA : xB, mode, T, offE);
-                                                idx = (diag_slot_selects(mode, T, lane, n) ? offE : off) + lane;
-                                                if (idx != diag_lane_index(g, off, useA ? xA : xB, lane, n)) return -13;
+                                            int T = 1 << 20;
+                                            for (int j = 0; j < nslots; ++j) {
+                                                const uint32_t d = rec[diag_slot_base(g.CH) + j];
+                                                if ((int)(d & 15) == i) T = (int)((d >> (useA ? 8 : 16)) & 255) - 64;
                                             }
+                                            const uint32_t x16 =
+                                                (rec[diag_xw_base(g.CH) + i / 2] >> (16 * (i & 1))) & 0xffff;
+                                            const int xA = x16 & 0x7fff;
+                                            int xB = xA;
+                                            if (x16 & 0x8000) xB = (xA + 1 == W) ? 0 : xA + 1;
+                                            const int x0 = useA ? xA : xB;
+                                            const int Tdev = x0 + 63 > W - 1 ? W - x0 : (x0 < k - 1 ? -x0 : 64);
+                                            if (T == (1 << 20)) {
+                                                if (!(hdr & 0x80000000u)) return -11;
+                                                T = Tdev;
+                                            } else if (T != Tdev) {
+                                                return -12;
+                                            }
+                                            if (diag_reads_extra(T, lane, n)) idx += g.gap;
+                                            // against the direct statement of the rule
+                                            const int off0 = (T <= 0) ? off + g.gap : off;
+                                            if (idx != diag_lane_index(g, off0, x0, lane, n)) return -13;
                                         }
                                         // tap weight
                                         const int ny = py + ky - g.p0, nx = px + kx - g.p0;
