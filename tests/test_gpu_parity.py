@@ -104,11 +104,14 @@ SHAPES = [  # B, C, H, W, k
     (1, 4, 31, 29, 1),         # 1x1 window
     # wide enough for the diagonal gather kernels (W >= 64 + k, H*W >= 4*C*k*k)
     (2, 21, 96, 112, 7),       # two channel splits of 11
-    (1, 19, 96, 128, 11),      # two channel splits of 10
+    (1, 19, 96, 128, 11),      # wide window: four channel splits of 5
     (1, 23, 70, 90, 5),        # three channel splits
     (2, 5, 40, 80, 5),
     (1, 9, 50, 75, 3),
     (1, 32, 90, 100, 3),
+    (1, 12, 100, 120, 9),      # 9x9: three channel splits of 5
+    (1, 19, 80, 100, 7),       # two channel splits of 10
+    (1, 17, 64, 70, 3),        # barely wide enough: most steps meet a row start (records with more flagged steps than slots)
 ]
 DIAG_SHAPES = SHAPES[10:]
 
