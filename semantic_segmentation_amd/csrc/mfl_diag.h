@@ -44,7 +44,9 @@ struct DiagGeom {
     int Hp, Wp, plane, gap;   // zero-padded plane; gap = Wp - W = k - 1
     int NB;                   // number of b values: ceil(L / CK)
     int NG;                   // groups: C*k
-    int NBB;                  // b-blocks of 64 lanes
+    int NBB;                  // b-blocks of 64 lanes the diagonal kernels run
+    int tail_lanes;           // lanes of one more, nearly empty b-block whose few pixels go to the tail
+                              // kernel instead (0: none)
     int NGW, NCS, CH;         // workgroup = NGW groups x NCS channel splits; CH channels per wave
     int NGB;                  // group blocks: ceil(NG / NGW)
     int RUN, RUNP;            // pixels of a workgroup along a (NGW*k) and the odd LDS pitch
@@ -109,6 +111,9 @@ MFL_HD int diag_slot_base(int CH) { return 2 * CH + 1; }
 MFL_HD int diag_xw_base(int CH) { return 2 * CH + 1 + kDiagSlots; }
 MFL_HD int diag_recw(int CH) { return ((diag_xw_base(CH) + (CH + 1) / 2 + 3) / 4) * 4; }
 
+// A last b-block with at most this many live lanes is not run by the diagonal kernels.
+constexpr int kDiagTailLanes = 16;
+
 // Returns 0 on success, -1 invalid, -3 too large for 32-bit indexing.
 inline int make_diag_geom(DiagGeom &g, int B, int C, int H, int W, int k, int lds_budget_bytes)
 {
@@ -122,6 +127,16 @@ inline int make_diag_geom(DiagGeom &g, int B, int C, int H, int W, int k, int ld
     g.NB = (int)((L + CK - 1) / CK);
     g.NG = C * k;
     g.NBB = (g.NB + k - 1 + 63) / 64;
+    g.tail_lanes = 0;
+    {
+        // a last block with only a few live lanes costs a whole workgroup for a handful of pixels:
+        // leave it to the per-pixel tail kernel
+        const int rem = g.NB + k - 1 - 64 * (g.NBB - 1);
+        if (g.NBB > 1 && rem <= kDiagTailLanes) {
+            g.tail_lanes = rem;
+            g.NBB -= 1;
+        }
+    }
     diag_split(C, k, g.CH, g.NCS, g.NGW);
     g.NGB = (g.NG + g.NGW - 1) / g.NGW;
     g.RUN = g.NGW * k;
@@ -256,6 +271,33 @@ MFL_HD void diag_fill_record(const DiagGeom &g, int beta, int gamma, int t, int 
 
 // Whether pixel n of lane `lane` reads the extra element of a side with threshold T.
 MFL_HD bool diag_reads_extra(int T, int lane, int n) { return lane - T >= n; }
+
+// Pixels of the b-block left to the tail kernel.  Pixel n of lane `lane` of that block has
+// b = 64 * NBB + lane - n, a pixel only while b < NB: diag_tail_lanes(n) lanes per n.  Candidate idx
+// in [0, NG * diag_tail_per_group) is (group, n, lane); diag_tail_pixel returns the output pixel l,
+// or -1 for a candidate past the end of the image (l >= L).
+MFL_HD int diag_tail_lanes(const DiagGeom &g, int n)
+{
+    const int m = g.NB - 64 * g.NBB + n;
+    return m < 0 ? 0 : (m < g.tail_lanes ? m : g.tail_lanes);
+}
+MFL_HD int diag_tail_per_group(const DiagGeom &g)
+{
+    int s = 0;
+    for (int n = 0; n < g.k; ++n) s += diag_tail_lanes(g, n);
+    return s;
+}
+MFL_HD long long diag_tail_candidates(const DiagGeom &g) { return (long long)g.NG * diag_tail_per_group(g); }
+MFL_HD int diag_tail_pixel(const DiagGeom &g, long long idx)
+{
+    const int per = diag_tail_per_group(g);
+    const int gamma = (int)(idx / per);
+    int r = (int)(idx - (long long)gamma * per), n = 0;
+    while (r >= diag_tail_lanes(g, n)) r -= diag_tail_lanes(g, n++);
+    const long long a = (long long)gamma * g.k + n, bb = 64LL * g.NBB + r - n;
+    const long long l = a + bb * g.CK;
+    return l < g.L ? (int)l : -1;
+}
 
 }  // namespace mfl
 

@@ -20,6 +20,7 @@ struct DiagArgs {
     const float *pos_w, *col_w;
     const float *unary, *aw, *ab;             // mode 0
     const float *compat;                     // mode 0: zero-padded to (CH*NCS)^2, or NULL
+    const float *compat_plain;               // mode 0: the caller's C x C matrix (tail pixels), or NULL
     float *logq, *qp_out;                    // mode 0: qp_out has the layout of xp
     float *y;                                // mode 1
     unsigned long long *dbg;                 // cycle stamps of diagnostic builds (-DMFL_STAMPS), else NULL

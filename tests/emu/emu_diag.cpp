@@ -112,6 +112,37 @@ extern "C" int emu_diag_local_forward(const float *x, const float *img, float pw
                                 y[((size_t)b * C + c) * Lz + l] = acc * x[((size_t)b * C + c) * Lz + l];
                             }
                     }
+        // the pixels of a nearly empty last b-block are enumerated for the tail kernel: computed here
+        // directly from the definition (the device tail kernel does the same per pixel)
+        for (long long idx = 0; g.tail_lanes && idx < diag_tail_candidates(g); ++idx) {
+            const int l = diag_tail_pixel(g, idx);
+            if (l < 0) continue;
+            count[(size_t)b * Lz + l] += 1;
+            const int py = l / W, px = l % W;
+            const float *xpad = buf.data() + g.FS + (size_t)b * per_image;
+            for (int c = 0; c < C; ++c) {
+                float acc = 0.f;
+                for (int t = 0; t < g.K; ++t) {
+                    const int ky = t / k, kx = t % k;
+                    const long long gg = ((long long)c * g.K + t) * g.L + l;
+                    const long long lp = gg / g.CK;
+                    const int rr = (int)(gg - lp * g.CK);
+                    const int cs = rr / g.K, ts = rr % g.K;
+                    const int ys = (int)(lp / W), xs = (int)(lp % W);
+                    const float val = xpad[(size_t)cs * g.plane + (ys + ts / k) * g.Wp + xs + ts % k];
+                    const int ny = py + ky - g.p0, nx = px + kx - g.p0;
+                    const bool in = ny >= 0 && ny < H && nx >= 0 && nx < W;
+                    float cd = 0.f;
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const float d = im[ch * Lz + l] - (in ? im[ch * Lz + (size_t)ny * W + nx] : 0.f);
+                        cd += d * d;
+                    }
+                    const int dy = ky - g.p0, dx = kx - g.p0;
+                    acc += ((float)(dy * dy + dx * dx) * pw + cd * cw) * val;
+                }
+                y[((size_t)b * C + c) * Lz + l] = acc * x[((size_t)b * C + c) * Lz + l];
+            }
+        }
     }
     return 0;
 }

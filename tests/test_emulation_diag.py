@@ -21,6 +21,8 @@ CASES = [  # B, C, H, W, k
     (1, 23, 70, 90, 5),        # three splits
     (1, 2, 128, 128, 3),       # BASELINE config 1 shape
     (1, 4, 30, 200, 9),
+    (1, 5, 35, 81, 3),         # a last b-block of 1 live lane: its pixels go to the tail kernel
+    (1, 8, 130, 200, 5),       # ... of 6 live lanes
 ]
 
 

@@ -111,6 +111,8 @@ SHAPES = [  # B, C, H, W, k
     (1, 32, 90, 100, 3),
     (1, 12, 100, 120, 9),      # 9x9: three channel splits of 5
     (1, 19, 80, 100, 7),       # two channel splits of 10
+    (1, 5, 35, 81, 3),         # a last b-block of 1 live lane: its pixels go to the tail kernel
+    (2, 8, 130, 200, 5),       # ... of 6 live lanes
     (1, 17, 64, 70, 3),        # barely wide enough: most steps meet a row start (records with more flagged steps than slots)
 ]
 DIAG_SHAPES = SHAPES[10:]
