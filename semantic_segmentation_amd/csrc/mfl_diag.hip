@@ -479,18 +479,166 @@ struct Loop {
     }
 };
 
+// The few pixels of a nearly empty last b-block (DiagGeom::tail_lanes) that the diagonal kernels
+// leave out, computed by extra workgroups at the end of the same launch (they fill the CUs that
+// the last round of regular workgroups leaves idle).  One wave per (image, group, chunk of 4 tail pixels); thread = (pixel, one of 16 channel
+// shares), so that the lanes of a load touch the two or three rows the group's pixels share instead
+// of one row each.  The index map (LocalConvolution.py:59-90 restated in mfl_core.h) is walked
+// incrementally over the taps: V index G(c, t+1) = G(c, t) + L, decoded through an LDS table of the
+// CK window offsets.  No workgroup barrier after the table: a wave's LDS traffic is ordered.
+// MODE 0: fused mean-field update   MODE 1: y = x * window sums
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int kTailPix = 4;      // pixels per wave
+constexpr int kTailShares = 16;  // threads per pixel
+
+template <int MODE>
+__device__ __forceinline__ void diag_tail_block(const DiagGeom &g, float *tail_lds, int tail_block, int nw, int per_group,
+                                                const float *__restrict__ xp, const F4 *__restrict__ ip4,
+                                                const float *__restrict__ pos_w, const float *__restrict__ col_w,
+                                                const float *__restrict__ unary, const float *__restrict__ aw,
+                                                const float *__restrict__ ab, const float *__restrict__ compat,
+                                                float *__restrict__ logq, float *__restrict__ qp_out,
+                                                float *__restrict__ y_out)
+{
+    const int chunks = (per_group + kTailPix - 1) / kTailPix;
+    const long long nwaves = (long long)g.B * g.NG * chunks;
+    const int C = g.C, K = g.K, k = g.k, W = g.W, Wp = g.Wp, L = g.L, CK = g.CK;
+    int *tab = reinterpret_cast<int *>(tail_lds);                 // [CK] window offsets
+    for (int r = threadIdx.x; r < CK; r += blockDim.x) {
+        const int cs = r / K, ts = r - cs * K;
+        const int tky = ts / k;
+        tab[r] = cs * g.plane + tky * Wp + (ts - tky * k);
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, tid = threadIdx.x & 63;
+    float *wbase = tail_lds + CK + wave * (kTailPix * (K + 2 * C));
+    float *wt = wbase;                          // [pixel][K] tap weights
+    float *mm = wbase + kTailPix * K;           // [pixel][C] messages
+    float *zz = mm + kTailPix * C;              // [pixel][C] unaries, then logits
+    const long long wslot = (long long)tail_block * nw + wave;
+    if (wslot >= nwaves) return;
+    const int img = (int)(wslot / ((long long)g.NG * chunks));
+    const int rem_w = (int)(wslot - (long long)img * g.NG * chunks);
+    const int gamma = rem_w / chunks, chunk = rem_w - gamma * chunks;
+    const int p = tid / kTailShares, share = tid - p * kTailShares;
+    const int pidx = chunk * kTailPix + p;      // pixel of the group's tail pixels
+    // (n, lane) of the pixel
+    int n = 0, lane = pidx;
+    bool valid = pidx < per_group;
+    if (valid) while (lane >= diag_tail_lanes(g, n)) lane -= diag_tail_lanes(g, n++);
+    const int bb = 64 * g.NBB + lane - n;
+    const long long l64 = (long long)gamma * k + n + (long long)bb * CK;
+    valid = valid && l64 < L;
+    const int l = valid ? (int)l64 : 0;
+    const int py = l / W, px = l - py * W;
+    const F4 *ip_b = ip4 + (size_t)img * g.plane;
+    const size_t img_off = (size_t)img * C * g.plane;
+    const float *in_b = xp + img_off + g.FS;
+    const int cpos = (py + g.p0) * Wp + px + g.p0;
+    const float pw = *pos_w, cw = *col_w;
+    {
+        const F4 ctr = ip_b[cpos];
+        for (int t = share; t < K; t += kTailShares) {
+            const int ky = t / k, kx = t - ky * k;
+            const F4 nb = ip_b[(py + ky) * Wp + px + kx];
+            const float d0 = ctr.x - nb.x, d1 = ctr.y - nb.y, d2 = ctr.z - nb.z;
+            const int dy = ky - g.p0, dx = kx - g.p0;
+            wt[p * K + t] = fmaf(fmaf(d2, d2, fmaf(d1, d1, d0 * d0)), cw, (float)(dy * dy + dx * dx) * pw);
+        }
+    }
+    wave_sync();
+    // channels share, share + kTailShares, ...: V index of (c, t = 0) for this pixel, then + L per tap
+    const unsigned qL = (unsigned)(L / CK), rL = (unsigned)(L - (long long)qL * CK);
+    for (int c = share; c < C; c += kTailShares) {
+        const unsigned long long g0 = (unsigned long long)c * K * (unsigned long long)L + (unsigned long long)l;
+        unsigned lp = (unsigned)(g0 / (unsigned)CK);
+        unsigned rr = (unsigned)(g0 - (unsigned long long)lp * (unsigned)CK);
+        float acc = 0.f;
+        // (16 loads in flight per thread: the loop is bound by their latency)
+#pragma unroll 16
+        for (int t = 0; t < K; ++t) {
+            const unsigned ys = lp / (unsigned)W, xs = lp - ys * (unsigned)W;
+            acc = fmaf(wt[p * K + t], in_b[tab[rr] + ys * Wp + xs], acc);
+            lp += qL;
+            rr += rL;
+            if (rr >= (unsigned)CK) { rr -= CK; ++lp; }
+        }
+        const float q = in_b[(size_t)c * g.plane + cpos];
+        if constexpr (MODE == 1) {
+            if (valid) y_out[((size_t)img * C + c) * L + l] = acc * q;
+        } else {
+            float m = acc * q;
+            if (aw) m = fmaf(aw[(size_t)c * L + l], m, ab[(size_t)c * L + l]);
+            mm[p * C + c] = m;
+            zz[p * C + c] = unary[((size_t)img * C + c) * L + l];
+        }
+    }
+    if constexpr (MODE == 0) {
+        wave_sync();
+        // every thread of the pixel reduces over all channels; it finishes its own channels
+        float mu = -INFINITY;
+        for (int c2 = 0; c2 < C; ++c2) mu = fmaxf(mu, zz[p * C + c2]);
+        float su = 0.f;
+        for (int c2 = 0; c2 < C; ++c2) su += __expf(zz[p * C + c2] - mu);
+        const float lse_u = mu + __logf(su);
+        float zmine[(64 + kTailShares - 1) / kTailShares];
+        int j = 0;
+        for (int c = share; c < C; c += kTailShares, ++j) {
+            float pv = mm[p * C + c];
+            if (compat) {
+                pv = 0.f;
+                for (int c2 = 0; c2 < C; ++c2) pv = fmaf(compat[c * C + c2], mm[p * C + c2], pv);
+            }
+            zmine[j] = (zz[p * C + c] - lse_u) - pv;
+        }
+        wave_sync();
+        j = 0;
+        for (int c = share; c < C; c += kTailShares, ++j) zz[p * C + c] = zmine[j];
+        wave_sync();
+        float mv = -INFINITY;
+        for (int c2 = 0; c2 < C; ++c2) mv = fmaxf(mv, zz[p * C + c2]);
+        float sv = 0.f;
+        for (int c2 = 0; c2 < C; ++c2) sv += __expf(zz[p * C + c2] - mv);
+        const float lse_v = mv + __logf(sv);
+        j = 0;
+        for (int c = share; c < C; c += kTailShares, ++j) {
+            const float lq = zmine[j] - lse_v;
+            if (valid) {
+                if (logq) logq[((size_t)img * C + c) * L + l] = lq;
+                qp_out[img_off + g.FS + (size_t)c * g.plane + cpos] = __expf(lq);
+            }
+        }
+    }
+}
+
+
 // MODE 0: fused mean-field update   MODE 1: y = x * window sums
 template <int CH, int KS, int NGW, int NCS, int MODE>
 __global__ void __launch_bounds__(64 * NGW * NCS)
-diag_kernel(DiagGeom g, int epi_rows, const float *__restrict__ xp, const F4 *__restrict__ ip4,
+diag_kernel(DiagGeom g, int epi_rows, int tail_per_group, const float *__restrict__ xp, const F4 *__restrict__ ip4,
             const uint32_t *__restrict__ table, const uint32_t *__restrict__ groups, const float *__restrict__ pos_w,
             const float *__restrict__ col_w, const float *__restrict__ unary, const float *__restrict__ aw,
-            const float *__restrict__ ab, const float *__restrict__ compat, float *__restrict__ logq,
-            float *__restrict__ qp_out, float *__restrict__ y_out, unsigned long long *__restrict__ dbg)
+            const float *__restrict__ ab, const float *__restrict__ compat, const float *__restrict__ compat_plain,
+            float *__restrict__ logq, float *__restrict__ qp_out, float *__restrict__ y_out,
+            unsigned long long *__restrict__ dbg)
 {
     MFL_STAMP(0);
     using Cfg = DiagCfg<CH, KS, NGW, NCS>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    {
+        // workgroups past the regular tiles: the pixels of a nearly empty last b-block
+        const int regular = g.NBB * g.NGB * g.B;
+        if ((int)blockIdx.x >= regular) {
+            diag_tail_block<MODE>(g, lds, (int)blockIdx.x - regular, NGW * NCS, tail_per_group, xp, ip4, pos_w, col_w, unary,
+                                  aw, ab, compat_plain, logq, qp_out, y_out);
+            return;
+        }
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int gi = wave % NGW, ci = wave / NGW;
@@ -753,21 +901,28 @@ int launch_cfg(const DiagArgs &a, int mode, hipStream_t st)
     using Cfg = DiagCfg<CH, KS, NGW, NCS>;
     const DiagGeom &g = a.g;
     if (g.CH != CH || g.k != KS || g.NGW != NGW || g.NCS != NCS) return MFL_ERR_INVALID_ARGUMENT;
-    const dim3 grid((unsigned)((size_t)g.NBB * g.NGB * g.B));
+    // regular tiles, then the workgroups of the tail pixels (one wave per chunk of kTailPix pixels)
+    const int tail_per_group = g.tail_lanes ? diag_tail_per_group(g) : 0;
+    const long long tail_waves = (long long)g.B * g.NG * ((tail_per_group + kTailPix - 1) / kTailPix);
+    const long long tail_blocks = (tail_waves + NGW * NCS - 1) / (NGW * NCS);
+    const long long blocks = (long long)g.NBB * g.NGB * g.B + tail_blocks;
+    if (blocks >= (1LL << 31)) return MFL_ERR_TOO_LARGE;
+    if (((size_t)g.CK + (size_t)NGW * NCS * kTailPix * (g.K + 2 * g.C)) * 4 > a.lds_bytes) return MFL_ERR_INVALID_ARGUMENT;
+    const dim3 grid((unsigned)blocks);
     const size_t lds = a.lds_bytes;
     hipError_t e;
     if (mode == 0) {
         auto kern = diag_kernel<CH, KS, NGW, NCS, 0>;
         e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), lds, st, a.g, a.epi_rows, a.xp, a.ip4, a.table, a.groups, a.pos_w, a.col_w,
-                           a.unary, a.aw, a.ab, a.compat, a.logq, a.qp_out, a.y, a.dbg);
+        hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), lds, st, a.g, a.epi_rows, tail_per_group, a.xp, a.ip4, a.table, a.groups, a.pos_w, a.col_w,
+                           a.unary, a.aw, a.ab, a.compat, a.compat_plain, a.logq, a.qp_out, a.y, a.dbg);
     } else {
         auto kern = diag_kernel<CH, KS, NGW, NCS, 1>;
         e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), lds, st, a.g, a.epi_rows, a.xp, a.ip4, a.table, a.groups, a.pos_w, a.col_w,
-                           a.unary, a.aw, a.ab, a.compat, a.logq, a.qp_out, a.y, a.dbg);
+        hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), lds, st, a.g, a.epi_rows, tail_per_group, a.xp, a.ip4, a.table, a.groups, a.pos_w, a.col_w,
+                           a.unary, a.aw, a.ab, a.compat, a.compat_plain, a.logq, a.qp_out, a.y, a.dbg);
     }
     return (int)hipGetLastError();
 }
