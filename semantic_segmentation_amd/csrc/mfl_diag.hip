@@ -495,6 +495,7 @@ __device__ __forceinline__ void wave_sync()
 
 constexpr int kTailPix = 4;      // pixels per wave
 constexpr int kTailShares = 16;  // threads per pixel
+constexpr int kTailChan = 3;     // channels per thread: the tail path serves up to 48 channels
 
 template <int MODE>
 __device__ __forceinline__ void diag_tail_block(const DiagGeom &g, float *tail_lds, int tail_block, int nw, int per_group,
@@ -552,30 +553,49 @@ __device__ __forceinline__ void diag_tail_block(const DiagGeom &g, float *tail_l
         }
     }
     wave_sync();
-    // channels share, share + kTailShares, ...: V index of (c, t = 0) for this pixel, then + L per tap
+    // channels share, share + kTailShares, ... (at most kTailChan per thread), walked together so that
+    // their loads overlap: V index of (c, t = 0) for this pixel, then + L per tap
     const unsigned qL = (unsigned)(L / CK), rL = (unsigned)(L - (long long)qL * CK);
-    for (int c = share; c < C; c += kTailShares) {
-        const unsigned long long g0 = (unsigned long long)c * K * (unsigned long long)L + (unsigned long long)l;
-        unsigned lp = (unsigned)(g0 / (unsigned)CK);
-        unsigned rr = (unsigned)(g0 - (unsigned long long)lp * (unsigned)CK);
-        float acc = 0.f;
-        // (16 loads in flight per thread: the loop is bound by their latency)
-#pragma unroll 16
-        for (int t = 0; t < K; ++t) {
-            const unsigned ys = lp / (unsigned)W, xs = lp - ys * (unsigned)W;
-            acc = fmaf(wt[p * K + t], in_b[tab[rr] + ys * Wp + xs], acc);
-            lp += qL;
-            rr += rL;
-            if (rr >= (unsigned)CK) { rr -= CK; ++lp; }
+    unsigned lp[kTailChan], rr[kTailChan];
+    float acc[kTailChan], qv[kTailChan], uv[kTailChan], av[kTailChan], bv[kTailChan];
+#pragma unroll
+    for (int j = 0; j < kTailChan; ++j) {
+        const int c = share + j * kTailShares;
+        const int cc = c < C ? c : 0;
+        const unsigned long long g0 = (unsigned long long)cc * K * (unsigned long long)L + (unsigned long long)l;
+        lp[j] = (unsigned)(g0 / (unsigned)CK);
+        rr[j] = (unsigned)(g0 - (unsigned long long)lp[j] * (unsigned)CK);
+        acc[j] = 0.f;
+        // what depends on (pixel, channel) only is requested before the taps
+        qv[j] = in_b[(size_t)cc * g.plane + cpos];
+        uv[j] = 0.f; av[j] = 1.f; bv[j] = 0.f;
+        if constexpr (MODE == 0) {
+            uv[j] = unary[((size_t)img * C + cc) * L + l];
+            if (aw) { av[j] = aw[(size_t)cc * L + l]; bv[j] = ab[(size_t)cc * L + l]; }
         }
-        const float q = in_b[(size_t)c * g.plane + cpos];
-        if constexpr (MODE == 1) {
-            if (valid) y_out[((size_t)img * C + c) * L + l] = acc * q;
-        } else {
-            float m = acc * q;
-            if (aw) m = fmaf(aw[(size_t)c * L + l], m, ab[(size_t)c * L + l]);
-            mm[p * C + c] = m;
-            zz[p * C + c] = unary[((size_t)img * C + c) * L + l];
+    }
+#pragma unroll 4
+    for (int t = 0; t < K; ++t) {
+        const float wv = wt[p * K + t];
+#pragma unroll
+        for (int j = 0; j < kTailChan; ++j) {
+            const unsigned ys = lp[j] / (unsigned)W, xs = lp[j] - ys * (unsigned)W;
+            acc[j] = fmaf(wv, in_b[tab[rr[j]] + ys * Wp + xs], acc[j]);
+            lp[j] += qL;
+            rr[j] += rL;
+            if (rr[j] >= (unsigned)CK) { rr[j] -= CK; ++lp[j]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kTailChan; ++j) {
+        const int c = share + j * kTailShares;
+        if (c < C) {
+            if constexpr (MODE == 1) {
+                if (valid) y_out[((size_t)img * C + c) * L + l] = acc[j] * qv[j];
+            } else {
+                mm[p * C + c] = fmaf(av[j], acc[j] * qv[j], bv[j]);
+                zz[p * C + c] = uv[j];
+            }
         }
     }
     if constexpr (MODE == 0) {
@@ -586,36 +606,43 @@ __device__ __forceinline__ void diag_tail_block(const DiagGeom &g, float *tail_l
         float su = 0.f;
         for (int c2 = 0; c2 < C; ++c2) su += __expf(zz[p * C + c2] - mu);
         const float lse_u = mu + __logf(su);
-        float zmine[(64 + kTailShares - 1) / kTailShares];
-        int j = 0;
-        for (int c = share; c < C; c += kTailShares, ++j) {
-            float pv = mm[p * C + c];
-            if (compat) {
-                pv = 0.f;
-                for (int c2 = 0; c2 < C; ++c2) pv = fmaf(compat[c * C + c2], mm[p * C + c2], pv);
+        float zmine[kTailChan];
+#pragma unroll
+        for (int j = 0; j < kTailChan; ++j) {
+            const int c = share + j * kTailShares;
+            zmine[j] = 0.f;
+            if (c < C) {
+                float pv = mm[p * C + c];
+                if (compat) {
+                    pv = 0.f;
+                    for (int c2 = 0; c2 < C; ++c2) pv = fmaf(compat[c * C + c2], mm[p * C + c2], pv);
+                }
+                zmine[j] = (zz[p * C + c] - lse_u) - pv;
             }
-            zmine[j] = (zz[p * C + c] - lse_u) - pv;
         }
         wave_sync();
-        j = 0;
-        for (int c = share; c < C; c += kTailShares, ++j) zz[p * C + c] = zmine[j];
+#pragma unroll
+        for (int j = 0; j < kTailChan; ++j) {
+            const int c = share + j * kTailShares;
+            if (c < C) zz[p * C + c] = zmine[j];
+        }
         wave_sync();
         float mv = -INFINITY;
         for (int c2 = 0; c2 < C; ++c2) mv = fmaxf(mv, zz[p * C + c2]);
         float sv = 0.f;
         for (int c2 = 0; c2 < C; ++c2) sv += __expf(zz[p * C + c2] - mv);
         const float lse_v = mv + __logf(sv);
-        j = 0;
-        for (int c = share; c < C; c += kTailShares, ++j) {
+#pragma unroll
+        for (int j = 0; j < kTailChan; ++j) {
+            const int c = share + j * kTailShares;
             const float lq = zmine[j] - lse_v;
-            if (valid) {
+            if (valid && c < C) {
                 if (logq) logq[((size_t)img * C + c) * L + l] = lq;
                 qp_out[img_off + g.FS + (size_t)c * g.plane + cpos] = __expf(lq);
             }
         }
     }
 }
-
 
 // MODE 0: fused mean-field update   MODE 1: y = x * window sums
 template <int CH, int KS, int NGW, int NCS, int MODE>
