@@ -175,7 +175,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "traffic_unit": "bytes per launch (PMC, committed passes)", "traffic_source": traffic_src,
-                         "kernel": "diag_kernel + diag_tail_kernel (one fused mean-field step)", "launch_ms": round(launch_ms, 4),
+                         "kernel": "diag_kernel (one fused mean-field step: regular tiles + tail workgroups)", "launch_ms": round(launch_ms, 4),
                          "bytes_per_launch": bytes_per_launch,
                          "valu": {"achieved": round(tflops, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": round(tflops / VALU_PEAK_TFLOPS, 4)}},
