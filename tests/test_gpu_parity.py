@@ -111,6 +111,12 @@ SHAPES = [  # B, C, H, W, k
     (1, 32, 90, 100, 3),
     (1, 12, 100, 120, 9),      # 9x9: three channel splits of 5
     (1, 19, 80, 100, 7),       # two channel splits of 10
+    (1, 6, 60, 100, 7),        # one split of 8, eight groups per workgroup
+    (1, 14, 64, 96, 5),        # two splits of 8
+    (1, 16, 64, 96, 7),
+    (1, 28, 80, 96, 5),        # three splits of 10
+    (1, 4, 60, 100, 11),       # wide windows: one split of 5
+    (1, 8, 64, 100, 9),        # ... two splits of 5
     (1, 5, 35, 81, 3),         # a last b-block of 1 live lane: its pixels go to the tail kernel
     (2, 8, 130, 200, 5),       # ... of 6 live lanes
     (1, 17, 64, 70, 3),        # barely wide enough: most steps meet a row start (records with more flagged steps than slots)
