@@ -154,16 +154,12 @@ __device__ __forceinline__ uint32_t rec_word(uint32_t recv, int j)
 // keep the fixed size MFL_CORR_STRIDE = 8*k + 4 bytes (2k 4-byte VOP2 + s_branch).
 #if MFL_DIAG_CH == 5
 #define MFL_CORR_LIST(M) M(0) M(1) M(2) M(3) M(4)
-#define MFL_CORR_CH "5"
 #elif MFL_DIAG_CH == 8
 #define MFL_CORR_LIST(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
-#define MFL_CORR_CH "8"
 #elif MFL_DIAG_CH == 10
 #define MFL_CORR_LIST(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9)
-#define MFL_CORR_CH "10"
 #elif MFL_DIAG_CH == 11
 #define MFL_CORR_LIST(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10)
-#define MFL_CORR_CH "11"
 #else
 #error "no correction step list for this MFL_DIAG_CH"
 #endif
