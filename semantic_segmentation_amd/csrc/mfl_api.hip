@@ -38,14 +38,16 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 __global__ void pad_planes_kernel(const float *__restrict__ src, float *__restrict__ dst, int planes, int H, int W,
                                   int Hp, int Wp, int p0)
 {
-    const size_t n = (size_t)planes * Hp * Wp;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int xx = (int)(i % Wp);
-        const size_t rest = i / Wp;
-        const int yy = (int)(rest % Hp);
-        const size_t pc = rest / Hp;
-        const int y = yy - p0, x = xx - p0;
-        dst[i] = (y >= 0 && y < H && x >= 0 && x < W) ? src[(pc * H + y) * W + x] : 0.0f;
+    // one padded row per workgroup pass: a single division per row, coalesced along x
+    const size_t rows = (size_t)planes * Hp;
+    for (size_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const size_t pc = row / Hp;
+        const int y = (int)(row - pc * Hp) - p0;
+        const bool inside = y >= 0 && y < H;
+        const float *s = src + (pc * H + (inside ? y : 0)) * W;
+        float *d = dst + row * Wp;
+        for (int xx = threadIdx.x; xx < Wp; xx += blockDim.x)
+            d[xx] = (inside && xx >= p0 && xx < W + p0) ? s[xx - p0] : 0.0f;
     }
 }
 
@@ -231,6 +233,7 @@ __global__ void reduce_partials_kernel(const float *__restrict__ partials, int n
 
 // ------------------------------------------------------------------ host side
 
+int pad_rows_grid(size_t rows) { return (int)(rows < 65535u * 16u ? rows : 65535u * 16u); }
 int grid_for(size_t n) { return (int)((n + kThreads - 1) / kThreads < 65535 * 16 ? (n + kThreads - 1) / kThreads : 65535 * 16); }
 
 // Channel-chunk widths the gather kernels are built for (mfl_gather.hip, -DMFL_CC=...).
@@ -293,7 +296,7 @@ int launch_prepare(const Geom &g, const float *x, const float *img, float *xp, F
 {
     if (x) {
         const size_t n = (size_t)g.B * g.C * g.plane;
-        hipLaunchKernelGGL(pad_planes_kernel, dim3(grid_for(n)), dim3(kThreads), 0, st, x, xp, g.B * g.C, g.H, g.W,
+        hipLaunchKernelGGL(pad_planes_kernel, dim3(pad_rows_grid((size_t)g.B * g.C * g.Hp)), dim3(kThreads), 0, st, x, xp, g.B * g.C, g.H, g.W,
                            g.Hp, g.Wp, g.p0);
         MFL_CHECK_HIP(hipMemsetAsync(xp + n, 0, padded_slack(g) * 4, st));
     }
@@ -457,7 +460,7 @@ int diag_prepare(const DiagGeom &g, const float *x, const float *img, float *x_f
 {
     const size_t n = (size_t)g.B * g.C * g.plane;
     MFL_CHECK_HIP(hipMemsetAsync(x_floats, 0, (size_t)g.FS * 4, st));
-    hipLaunchKernelGGL(pad_planes_kernel, dim3(grid_for(n)), dim3(kThreads), 0, st, x, x_floats + g.FS, g.B * g.C, g.H,
+    hipLaunchKernelGGL(pad_planes_kernel, dim3(pad_rows_grid((size_t)g.B * g.C * g.Hp)), dim3(kThreads), 0, st, x, x_floats + g.FS, g.B * g.C, g.H,
                        g.W, g.Hp, g.Wp, g.p0);
     MFL_CHECK_HIP(hipMemsetAsync(x_floats + g.FS + n, 0, (3 * (size_t)g.Wp + 64) * 4, st));
     const size_t ni = (size_t)g.B * g.plane;
