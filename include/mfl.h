@@ -12,9 +12,9 @@
  *   LinearActivation (per-pixel affine)     AdvancedModel.py:38-56
  *
  * The reference has no FFI of its own (it is pure Python); each entry point
- * below names the Python symbol whose arithmetic it takes over, and
- * INTEGRATION.md shows the ctypes binding a maintainer adds on the reference
- * side.
+ * below names the Python symbol whose arithmetic it takes over; the binding a
+ * maintainer adds on the reference side is a ctypes one
+ * (semantic_segmentation_amd/_lib.py is such a binding).
  *
  * Conventions
  *   - plain C, no torch types; every pointer is a BORROWED device pointer that
