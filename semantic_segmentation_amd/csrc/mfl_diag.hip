@@ -56,6 +56,9 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, int voff, ui
 #ifdef MFL_ABL_NO_LOADS
     return __builtin_bit_cast(float, (uint32_t)voff + soff);
 #endif
+#ifdef MFL_ABL_SMALL_WINDOW
+    soff &= MFL_ABL_SMALL_WINDOW;    // timing experiment: every element load inside one small window
+#endif
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, (int)soff, 0));
 }
 
