@@ -406,7 +406,51 @@ int launch_diag_table(const DiagGeom &g, uint32_t *table, uint32_t *groups, hipS
 
 struct DiagWorkspace {
     size_t xp, xp2, ip4, table, groups, compat, total;
+    size_t psum, qsum, consts, partials;     // backward only
 };
+
+constexpr int kDiagBackwardBlocks = 2048;    // blocks (and partial sums) of the backward's finishing pass
+
+__global__ void diag_backward_consts_kernel(float *c)
+{
+    if (threadIdx.x == 0) { c[0] = 1.f; c[1] = 0.f; c[2] = 0.f; c[3] = 1.f; }
+}
+
+// dx = dy * (pos_w * P + col_w * Q) + scattered term (interior of the padded gradient planes);
+// partials[2*block + {0,1}] = sum of dy * x * {P, Q} (gradients of position_weight / color_weight),
+// where P / Q are the window sums with weights pd[t] / cd[l,t] alone (LocalConvolution.py:84-90).
+__global__ void __launch_bounds__(kThreads)
+diag_backward_finish_kernel(const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ P,
+                            const float *__restrict__ Q, const float *__restrict__ dxp, const float *__restrict__ pos_w,
+                            const float *__restrict__ col_w, float *__restrict__ dx, float *__restrict__ partials,
+                            int planes, int H, int W, int Hp, int Wp, int p0)
+{
+    __shared__ float sh[2][kThreads];
+    const float pw = *pos_w, cw = *col_w;
+    const size_t n = (size_t)planes * H * W;
+    float a = 0.f, c = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % W);
+        const size_t rest = i / W;
+        const int yy = (int)(rest % H);
+        const size_t pc = rest / H;
+        const float p = P[i], q = Q[i], g = dy[i], d = g * x[i];
+        dx[i] = fmaf(g, fmaf(pw, p, cw * q), dxp[(pc * Hp + yy + p0) * Wp + xx + p0]);
+        a = fmaf(d, p, a);
+        c = fmaf(d, q, c);
+    }
+    sh[0][threadIdx.x] = a;
+    sh[1][threadIdx.x] = c;
+    __syncthreads();
+    for (int s = kThreads / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = sh[0][0]; partials[2 * blockIdx.x + 1] = sh[1][0]; }
+}
 
 // dst[CE][CE] = src[C][C] zero-padded: constant row pitch for the fused epilogue's scalar loads
 // dst[c2][c] = src[c][c2], zero-padded to CE2 x CE2 (CE2 even): the layout the fused epilogue reads
@@ -431,13 +475,20 @@ DiagWorkspace diag_carve(int op, const DiagGeom &g)
     w.table = take(diag_table_dwords(g) * 4);
     w.groups = take((size_t)g.k * g.k * 4);
     w.compat = take((size_t)(g.CH * g.NCS + 1) * (g.CH * g.NCS + 1) * 4);
+    if (op == MFL_OP_LOCAL_BACKWARD) {
+        w.xp2 = take(diag_padded_floats(g) * 4);          // the padded gradient planes
+        w.psum = take((size_t)g.B * g.C * g.L * 4);
+        w.qsum = take((size_t)g.B * g.C * g.L * 4);
+        w.consts = take(4 * 4);
+        w.partials = take((size_t)2 * kDiagBackwardBlocks * 4);
+    }
     w.total = off;
     return w;
 }
 
 bool diag_eligible(int op, int B, int C, int H, int W, int k, DiagGeom &g)
 {
-    if (op != MFL_OP_LOCAL_FORWARD && op != MFL_OP_MEANFIELD_FORWARD) return false;
+    if (op != MFL_OP_LOCAL_FORWARD && op != MFL_OP_MEANFIELD_FORWARD && op != MFL_OP_LOCAL_BACKWARD) return false;
     if (op == MFL_OP_MEANFIELD_FORWARD && C > 32) return false;
     return make_diag_geom(g, B, C, H, W, k, kDiagWeightLds) == 0;
 }
@@ -510,10 +561,14 @@ size_t mfl_workspace_bytes(int op, int B, int C, int H, int W, int k, int iters)
     (void)iters;
     if (op != MFL_OP_LOCAL_FORWARD && op != MFL_OP_LOCAL_BACKWARD && op != MFL_OP_MEANFIELD_FORWARD) return 0;
     DiagGeom dg;
-    if (diag_eligible(op, B, C, H, W, k, dg)) return diag_carve(op, dg).total;
+    const bool diag = diag_eligible(op, B, C, H, W, k, dg);
+    if (diag && op != MFL_OP_LOCAL_BACKWARD) return diag_carve(op, dg).total;
     Geom g;
     if (make_geom(g, B, C, H, W, k, 1)) return 0;
-    return carve(op, g, pick_cc(C)).total;
+    const size_t generic = carve(op, g, pick_cc(C)).total;
+    // the backward takes the diagonal kernels with an image and the generic ones with a cd tensor
+    if (diag) { const size_t d = diag_carve(op, dg).total; return d > generic ? d : generic; }
+    return generic;
 }
 
 int mfl_color_distance(const float *img, float *cd, int B, int H, int W, int k, mfl_stream_t stream)
@@ -581,6 +636,46 @@ int mfl_local_backward(const float *x, const float *img, const float *cd, const 
     if (rc) return rc;
     if (!dx || !dparams || !pos_w || !col_w || (img == nullptr) == (cd == nullptr)) return MFL_ERR_INVALID_ARGUMENT;
     if (dcd && !cd) return MFL_ERR_INVALID_ARGUMENT;
+    DiagGeom dg;
+    if (img && diag_eligible(MFL_OP_LOCAL_BACKWARD, B, C, H, W, k, dg)) {
+        // dx = dy * S + scatter, S = pos_w * P + col_w * Q: two gathers with the weights (1, 0) and
+        // (0, 1) give P and Q (and with them both parameter gradients), one scatter launch the rest
+        const DiagWorkspace ws = diag_carve(MFL_OP_LOCAL_BACKWARD, dg);
+        if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
+        char *base = (char *)workspace;
+        hipStream_t st = (hipStream_t)stream;
+        rc = diag_prepare(dg, x, img, (float *)(base + ws.xp), (F4 *)(base + ws.ip4), (uint32_t *)(base + ws.table),
+                          (uint32_t *)(base + ws.groups), st);
+        if (rc) return rc;
+        float *consts = (float *)(base + ws.consts), *P = (float *)(base + ws.psum), *Q = (float *)(base + ws.qsum);
+        float *dxp = (float *)(base + ws.xp2), *partials = (float *)(base + ws.partials);
+        hipLaunchKernelGGL(diag_backward_consts_kernel, dim3(1), dim3(64), 0, st, consts);
+        MFL_CHECK_HIP(hipMemsetAsync(dxp, 0, diag_padded_floats(dg) * 4, st));
+        DiagArgs da{};
+        da.g = dg;
+        diag_lds(dg, da);
+        da.xp = (const float *)(base + ws.xp);
+        da.ip4 = (const F4 *)(base + ws.ip4);
+        da.table = (const uint32_t *)(base + ws.table);
+        da.groups = (const uint32_t *)(base + ws.groups);
+        da.pos_w = consts; da.col_w = consts + 1; da.y = P;
+        rc = dispatch_diag(da, 2, st);
+        if (rc) return rc;
+        da.pos_w = consts + 2; da.col_w = consts + 3; da.y = Q;
+        rc = dispatch_diag(da, 2, st);
+        if (rc) return rc;
+        da.pos_w = pos_w; da.col_w = col_w; da.y = nullptr;
+        da.unary = dy;
+        da.qp_out = dxp;
+        rc = dispatch_diag(da, 3, st);
+        if (rc) return rc;
+        const size_t n = (size_t)B * C * dg.L;
+        const int blocks = grid_for(n) < kDiagBackwardBlocks ? grid_for(n) : kDiagBackwardBlocks;
+        hipLaunchKernelGGL(diag_backward_finish_kernel, dim3(blocks), dim3(kThreads), 0, st, dy, x, P, Q, dxp + dg.FS, pos_w,
+                           col_w, dx, partials, B * C, H, W, dg.Hp, dg.Wp, dg.p0);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kThreads), 0, st, partials, blocks, dparams);
+        return (int)hipGetLastError();
+    }
     Geom g;
     int cc;
     bool tab_lds;

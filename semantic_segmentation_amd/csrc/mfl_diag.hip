@@ -219,9 +219,12 @@ __device__ __forceinline__ uint32_t rec_word(uint32_t recv, int j)
                  : MFL_KS_LIST(MFL_CORR_IN, 0) MFL_CORR_LIST(MFL_CORR_XS)[st] "s"(step)                   \
                  : "vcc", "scc", "s96", "s97", "s98", "s99")
 
-template <int CH, int KS, int NGW, int NCS>
+// BWD: the scatter of the backward pass (tap_scatter) instead of the gather (tap)
+template <int CH, int KS, int NGW, int NCS, bool BWD>
 struct Loop {
     using Cfg = DiagCfg<CH, KS, NGW, NCS>;
+    float *scatter_out;                     // BWD: FS floats before the image's zeroed padded gradient planes
+    int C, ci;                              // BWD: channels, this wave's channel split
     DiagState<CH, KS, NGW, NCS> &st;
     __amdgpu_buffer_rsrc_t rsrc;
     const uint32_t *__restrict__ table;    // records of this wave's (b-block, group, channel split), tap 0
@@ -348,6 +351,10 @@ struct Loop {
         const int wbase = (lane + KS - 1) * Cfg::RUNP + gi * KS;
 #pragma unroll
         for (int n = 0; n < KS; ++n) w[n] = wt_tap[wbase - n * (Cfg::RUNP - 1)];
+        if constexpr (BWD) {
+            tap_scatter<SA>(w);
+            return;
+        }
         const uint32_t rec_new = request_record();
         const int voff = lane * 4;
         MFL_SEG(0);
@@ -374,6 +381,57 @@ struct Loop {
             v.B[i] = buf_load(rsrc, voff, rec_word(rec_pre, CH + i));
         }
         MFL_SEG(3);
+        rec_use = rec_pre;
+        rec_pre = rec_req;
+        rec_req = rec_new;
+    }
+
+    // Backward of one tap (the transpose of tap()): st.acc holds D = dy * x of the lane's pixels; what
+    // the k pixels of a side send to their shared element is summed and added to the gradient planes
+    // with one float atomic per lane (64 consecutive floats per wave).  A flagged side splits the sum
+    // between the shared and the extra element by the same rule the gather reads them.
+    template <int SA>
+    __device__ __forceinline__ void tap_scatter(const float (&w)[KS])
+    {
+        const uint32_t rec_new = request_record();
+        const uint32_t hdr = rec_word(rec_use, 2 * CH);
+        float *base = scatter_out + lane;
+        constexpr int NA = KS - SA;
+        auto threshold = [&](int x0) { return x0 + 63 > W - 1 ? W - x0 : (x0 < KS - 1 ? -x0 : 64); };
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            if (ci * CH + i < C) {
+                const uint32_t oA = rec_word(rec_use, i) >> 2, oB = rec_word(rec_use, CH + i) >> 2;
+                if ((hdr >> i) & 1) {
+                    const uint32_t x16 = (rec_word(rec_use, diag_xw_base(CH) + (i >> 1)) >> (16 * (i & 1))) & 0xffffu;
+                    const int xA = x16 & 0x7fff;
+                    const int xB = (x16 & 0x8000) ? (xA + 1 == W ? 0 : xA + 1) : xA;
+                    const int pA = lane - threshold(xA), pB = lane - threshold(xB);
+                    float sA = 0.f, eA = 0.f, sB = 0.f, eB = 0.f;
+#pragma unroll
+                    for (int n = 0; n < KS; ++n) {
+                        const float t = w[n] * st.acc[i][n];
+                        if (n < NA) { if (pA >= n) eA += t; else sA += t; }
+                        else { if (pB >= n) eB += t; else sB += t; }
+                    }
+                    unsafeAtomicAdd(base + oA, sA);
+                    unsafeAtomicAdd(base + oA + (gap4 >> 2), eA);
+                    if constexpr (SA > 0) {
+                        unsafeAtomicAdd(base + oB, sB);
+                        unsafeAtomicAdd(base + oB + (gap4 >> 2), eB);
+                    }
+                } else {
+                    float dA = 0.f, dB = 0.f;
+#pragma unroll
+                    for (int n = 0; n < KS; ++n) {
+                        if (n < NA) dA = fmaf(w[n], st.acc[i][n], dA);
+                        else dB = fmaf(w[n], st.acc[i][n], dB);
+                    }
+                    unsafeAtomicAdd(base + oA, dA);
+                    if constexpr (SA > 0) unsafeAtomicAdd(base + oB, dB);
+                }
+            }
+        }
         rec_use = rec_pre;
         rec_pre = rec_req;
         rec_req = rec_new;
@@ -464,12 +522,14 @@ struct Loop {
             rec_use = request_record();      // tap 0
             rec_pre = request_record();      // tap 1
             rec_req = request_record();      // tap 2
-            const int voff = lane * 4;
+            if constexpr (!BWD) {
+                const int voff = lane * 4;
 #pragma unroll
-            for (int i = 0; i < CH; ++i) v.A[i] = buf_load(rsrc, voff, rec_word(rec_use, i));
+                for (int i = 0; i < CH; ++i) v.A[i] = buf_load(rsrc, voff, rec_word(rec_use, i));
 #pragma unroll
-            for (int i = 0; i < CH; ++i) v.B[i] = buf_load(rsrc, voff, rec_word(rec_use, CH + i));
-            load_slots(rec_use);
+                for (int i = 0; i < CH; ++i) v.B[i] = buf_load(rsrc, voff, rec_word(rec_use, CH + i));
+                load_slots(rec_use);
+            }
         }
         WeightPhase<CH, KS, NGW, NCS>::run(st, p0, Wp, irsrc, pw, cw, groups[0], lds);
         __syncthreads();
@@ -568,18 +628,21 @@ __device__ __forceinline__ void diag_tail_block(const DiagGeom &g, float *tail_l
         // what depends on (pixel, channel) only is requested before the taps
         qv[j] = in_b[(size_t)cc * g.plane + cpos];
         uv[j] = 0.f; av[j] = 1.f; bv[j] = 0.f;
+        if constexpr (MODE == 0 || MODE == 3) uv[j] = unary[((size_t)img * C + cc) * L + l];
         if constexpr (MODE == 0) {
-            uv[j] = unary[((size_t)img * C + cc) * L + l];
             if (aw) { av[j] = aw[(size_t)cc * L + l]; bv[j] = ab[(size_t)cc * L + l]; }
         }
+        if constexpr (MODE == 3) qv[j] = (valid && c < C) ? qv[j] * uv[j] : 0.f;   // D = dy * x
     }
+    float *grad_b = qp_out + img_off + g.FS;
 #pragma unroll 4
     for (int t = 0; t < K; ++t) {
         const float wv = wt[p * K + t];
 #pragma unroll
         for (int j = 0; j < kTailChan; ++j) {
             const unsigned ys = lp[j] / (unsigned)W, xs = lp[j] - ys * (unsigned)W;
-            acc[j] = fmaf(wv, in_b[tab[rr[j]] + ys * Wp + xs], acc[j]);
+            if constexpr (MODE == 3) unsafeAtomicAdd(grad_b + tab[rr[j]] + ys * Wp + xs, wv * qv[j]);
+            else acc[j] = fmaf(wv, in_b[tab[rr[j]] + ys * Wp + xs], acc[j]);
             lp[j] += qL;
             rr[j] += rL;
             if (rr[j] >= (unsigned)CK) { rr[j] -= CK; ++lp[j]; }
@@ -589,9 +652,9 @@ __device__ __forceinline__ void diag_tail_block(const DiagGeom &g, float *tail_l
     for (int j = 0; j < kTailChan; ++j) {
         const int c = share + j * kTailShares;
         if (c < C) {
-            if constexpr (MODE == 1) {
-                if (valid) y_out[((size_t)img * C + c) * L + l] = acc[j] * qv[j];
-            } else {
+            if constexpr (MODE == 1 || MODE == 2) {
+                if (valid) y_out[((size_t)img * C + c) * L + l] = MODE == 1 ? acc[j] * qv[j] : acc[j];
+            } else if constexpr (MODE == 0) {
                 mm[p * C + c] = fmaf(av[j], acc[j] * qv[j], bv[j]);
                 zz[p * C + c] = uv[j];
             }
@@ -643,7 +706,9 @@ __device__ __forceinline__ void diag_tail_block(const DiagGeom &g, float *tail_l
     }
 }
 
-// MODE 0: fused mean-field update   MODE 1: y = x * window sums
+// MODE 0: fused mean-field update   MODE 1: y = x * window sums   MODE 2: y = window sums
+// MODE 3: backward scatter: gradient planes (qp_out, zeroed by the caller) += transpose of the window
+//         sums applied to D = dy * x (dy passed as `unary`)
 template <int CH, int KS, int NGW, int NCS, int MODE>
 __global__ void __launch_bounds__(64 * NGW * NCS)
 diag_kernel(DiagGeom g, int epi_rows, int tail_per_group, const float *__restrict__ xp, const F4 *__restrict__ ip4,
@@ -707,19 +772,6 @@ diag_kernel(DiagGeom g, int epi_rows, int tail_per_group, const float *__restric
     }
     const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ip_b, 0, 0x7fffffff, 0x00020000);
 
-    Loop<CH, KS, NGW, NCS> loop{st, rsrc, table + diag_record_index(g, beta, live ? gamma : 0, 0, ci), groups, irsrc, lds,
-                                pw, cw, g.ngroups, g.TB, g.NCS * g.RECW, g.RECW, g.p0, Wp, W, g.gap * 4, gi, lane, live,
-                                dbg};
-    MFL_STAMP(1);
-    loop.run();
-    if (loop.touched == 0xfeedbeefu && g.B < 0) y_out[0] = 1.f;   // keeps the record prefetch loads alive
-    MFL_STAMP(40);
-#ifdef MFL_STAMPS
-    if (dbg && blockIdx.x < 256 && threadIdx.x == 0)
-        for (int i = 0; i < 6; ++i) dbg[blockIdx.x * 64 + 54 + i] = loop.seg[i];
-#endif
-
-    // ---- epilogue: accumulators -> LDS [channel][b_rel][a_rel], then one pixel per thread ----
     const int CBR = epi_rows;
     const int cstride = CBR * Cfg::RUNP;
     // pixel r of the chunk starting at b row cb0: LDS place, output pixel l and centre position in
@@ -739,6 +791,50 @@ diag_kernel(DiagGeom g, int epi_rows, int tail_per_group, const float *__restric
         moff = ok ? br * Cfg::RUNP + a_rel : 0;
         return ok;
     };
+    if constexpr (MODE == 3) {
+        // backward: D = dy * x of the workgroup's pixels goes through LDS the other way round (threads
+        // load whole pixels, coalesced; lanes pick up their diagonals), chunk by chunk
+        for (int cb0 = 0; cb0 < Cfg::NBR; cb0 += CBR) {
+            const int rows = (Cfg::NBR - cb0 < CBR) ? Cfg::NBR - cb0 : CBR;
+            const int cnt = rows * Cfg::RUN;
+            for (int r = tid; r < cnt; r += Cfg::NT) {
+                int moff, l, cpos;
+                const bool ok = place(cb0, r, moff, l, cpos);
+                const int br = r / Cfg::RUN, a_rel = r - br * Cfg::RUN;
+                float *dst = lds + br * Cfg::RUNP + a_rel;
+                const float *dy_b = unary + (size_t)img * C * L + l;
+                const float *xc = in_b + g.FS + cpos;
+                for (int c = 0; c < Cfg::CE; ++c)
+                    dst[c * cstride] = (ok && c < C) ? dy_b[(size_t)c * L] * xc[(size_t)c * g.plane] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int n = 0; n < KS; ++n) {
+                const int br = lane - n + KS - 1 - cb0;
+                if (br >= 0 && br < CBR) {
+                    const float *src = lds + (ci * CH * CBR + br) * Cfg::RUNP + gi * KS + n;
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) st.acc[i][n] = src[i * cstride];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    Loop<CH, KS, NGW, NCS, MODE == 3> loop{qp_out + img_off, C, ci, st, rsrc,
+                                           table + diag_record_index(g, beta, live ? gamma : 0, 0, ci), groups, irsrc, lds,
+                                           pw, cw, g.ngroups, g.TB, g.NCS * g.RECW, g.RECW, g.p0, Wp, W, g.gap * 4, gi,
+                                           lane, live, dbg};
+    MFL_STAMP(1);
+    loop.run();
+    if constexpr (MODE == 3) return;
+    if (loop.touched == 0xfeedbeefu && g.B < 0) y_out[0] = 1.f;   // keeps the record prefetch loads alive
+    MFL_STAMP(40);
+#ifdef MFL_STAMPS
+    if (dbg && blockIdx.x < 256 && threadIdx.x == 0)
+        for (int i = 0; i < 6; ++i) dbg[blockIdx.x * 64 + 54 + i] = loop.seg[i];
+#endif
+
+    // ---- epilogue: accumulators -> LDS [channel][b_rel][a_rel], then one pixel per thread ----
     // accumulators of the b rows [cb0, cb0 + CBR) -> LDS.  The tile has room for all CH * NCS channel
     // rows, so the padded channels of the last split are written without a guard and never read.
     auto transpose = [&](int cb0) {
@@ -754,7 +850,7 @@ diag_kernel(DiagGeom g, int epi_rows, int tail_per_group, const float *__restric
             }
         }
     };
-    if constexpr (MODE == 1) {
+    if constexpr (MODE == 1 || MODE == 2) {
         for (int cb0 = 0; cb0 < Cfg::NBR; cb0 += CBR) {
             transpose(cb0);
             __syncthreads();
@@ -770,7 +866,8 @@ diag_kernel(DiagGeom g, int epi_rows, int tail_per_group, const float *__restric
                 const float *msg = lds + moff;
                 const float *qc = in_b + g.FS + cpos;
                 float *y_b = y_out + (size_t)img * C * L + l;
-                for (int c = 0; c < C; ++c) y_b[(size_t)c * L] = msg[c * cstride] * qc[(size_t)c * g.plane];
+                for (int c = 0; c < C; ++c)
+                    y_b[(size_t)c * L] = MODE == 1 ? msg[c * cstride] * qc[(size_t)c * g.plane] : msg[c * cstride];
             }
             __syncthreads();
         }
@@ -936,20 +1033,22 @@ int launch_cfg(const DiagArgs &a, int mode, hipStream_t st)
     if (((size_t)g.CK + (size_t)NGW * NCS * kTailPix * (g.K + 2 * g.C)) * 4 > a.lds_bytes) return MFL_ERR_INVALID_ARGUMENT;
     const dim3 grid((unsigned)blocks);
     const size_t lds = a.lds_bytes;
-    hipError_t e;
-    if (mode == 0) {
-        auto kern = diag_kernel<CH, KS, NGW, NCS, 0>;
-        e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto go = [&](auto kern) -> int {
+        const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), lds, st, a.g, a.epi_rows, tail_per_group, a.xp, a.ip4, a.table, a.groups, a.pos_w, a.col_w,
-                           a.unary, a.aw, a.ab, a.compat, a.compat_plain, a.logq, a.qp_out, a.y, a.dbg);
-    } else {
-        auto kern = diag_kernel<CH, KS, NGW, NCS, 1>;
-        e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), lds, st, a.g, a.epi_rows, tail_per_group, a.xp, a.ip4, a.table, a.groups, a.pos_w, a.col_w,
-                           a.unary, a.aw, a.ab, a.compat, a.compat_plain, a.logq, a.qp_out, a.y, a.dbg);
+        hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), lds, st, a.g, a.epi_rows, tail_per_group, a.xp, a.ip4, a.table, a.groups,
+                           a.pos_w, a.col_w, a.unary, a.aw, a.ab, a.compat, a.compat_plain, a.logq, a.qp_out, a.y, a.dbg);
+        return 0;
+    };
+    int rc;
+    switch (mode) {
+    case 0: rc = go(diag_kernel<CH, KS, NGW, NCS, 0>); break;
+    case 1: rc = go(diag_kernel<CH, KS, NGW, NCS, 1>); break;
+    case 2: rc = go(diag_kernel<CH, KS, NGW, NCS, 2>); break;
+    case 3: rc = go(diag_kernel<CH, KS, NGW, NCS, 3>); break;
+    default: return MFL_ERR_INVALID_ARGUMENT;
     }
+    if (rc) return rc;
     return (int)hipGetLastError();
 }
 
