@@ -1,7 +1,7 @@
 """Geometry sweep of the diagonal gather kernels on the GPU: for seeded random shapes that the fast
-path accepts, the image-mode local forward (diagonal kernels, possibly with tail workgroups and
-overflow records) must agree with the tensor-mode one (generic kernels fed a materialised
-colour-distance tensor), and one mean-field step must agree with its composition from the separate
+path accepts, the image-mode local forward and backward (diagonal kernels, possibly with tail
+workgroups and overflow records) must agree with the tensor-mode ones (generic kernels fed a
+materialised colour-distance tensor), and one mean-field step must agree with its composition from the separate
 entry points.  The generic kernels are pinned against the oracle in test_gpu_parity.py; this sweep
 covers many more alignments (L % k, tails, row-start patterns) than the oracle could in seconds."""
 import numpy as np
@@ -45,6 +45,13 @@ def test_diagonal_kernels_agree_with_generic_kernels(shape, S):
     cd = S.ops.color_distance(img, k)
     y_gen = S.ops.local_forward(x, pw, cw, k, cd=cd)
     assert_close(y_fast.cpu().numpy(), y_gen.cpu().numpy(), 1e-4, f"local forward {shape}")
+    # backward: scatter on the diagonal kernels against the generic kernels' atomics
+    dy = torch.from_numpy(rng.standard_normal((B, C, H, W)).astype(np.float32)).cuda()
+    dx_fast, dpar_fast, _ = S.ops.local_backward(x, pw, cw, k, dy, image=img)
+    dx_gen, dpar_gen, _ = S.ops.local_backward(x, pw, cw, k, dy, cd=cd)
+    assert_close(dx_fast.cpu().numpy(), dx_gen.cpu().numpy(), 1e-4, f"local backward dx {shape}")
+    a, b = dpar_fast.cpu().numpy().astype(np.float64), dpar_gen.cpu().numpy().astype(np.float64)
+    assert np.all(np.abs(a - b) <= 2e-4 * np.abs(b) + 1e-5 * np.abs(b).max()), (a, b)
     # one fused mean-field step = local forward of the unary + combine
     compat = torch.from_numpy(((1 - np.eye(C)) + 0.01 * rng.standard_normal((C, C))).astype(np.float32)).cuda()
     lq = S.ops.meanfield_forward(x, img, pw * 0.01, cw * 0.01, k, 1, None, None, compat)
