@@ -490,7 +490,7 @@ bool diag_eligible(int op, int B, int C, int H, int W, int k, DiagGeom &g)
 {
     if (op != MFL_OP_LOCAL_FORWARD && op != MFL_OP_MEANFIELD_FORWARD && op != MFL_OP_LOCAL_BACKWARD) return false;
     if (op == MFL_OP_MEANFIELD_FORWARD && C > 32) return false;
-    return make_diag_geom(g, B, C, H, W, k, kDiagWeightLds) == 0;
+    return make_diag_geom(g, B, C, H, W, k, kDiagWeightLds, op != MFL_OP_LOCAL_BACKWARD) == 0;
 }
 
 int dispatch_diag(const DiagArgs &a, int mode, hipStream_t st)

@@ -111,11 +111,13 @@ MFL_HD int diag_slot_base(int CH) { return 2 * CH + 1; }
 MFL_HD int diag_xw_base(int CH) { return 2 * CH + 1 + kDiagSlots; }
 MFL_HD int diag_recw(int CH) { return ((diag_xw_base(CH) + (CH + 1) / 2 + 3) / 4) * 4; }
 
-// A last b-block with at most this many live lanes is not run by the diagonal kernels.
+// A last b-block with at most this many live lanes is not run by the diagonal kernels (unless the
+// caller asks for all blocks: the backward does, its tail pixels would scatter one 4-byte atomic per
+// lane to unrelated lines, which costs far more than the nearly empty workgroups).
 constexpr int kDiagTailLanes = 16;
 
 // Returns 0 on success, -1 invalid, -3 too large for 32-bit indexing.
-inline int make_diag_geom(DiagGeom &g, int B, int C, int H, int W, int k, int lds_budget_bytes)
+inline int make_diag_geom(DiagGeom &g, int B, int C, int H, int W, int k, int lds_budget_bytes, bool allow_tail = true)
 {
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0) return -1;
     if (!diag_supported(C, H, W, k)) return -1;
@@ -132,7 +134,7 @@ inline int make_diag_geom(DiagGeom &g, int B, int C, int H, int W, int k, int ld
         // a last block with only a few live lanes costs a whole workgroup for a handful of pixels:
         // leave it to the per-pixel tail kernel
         const int rem = g.NB + k - 1 - 64 * (g.NBB - 1);
-        if (g.NBB > 1 && rem <= kDiagTailLanes) {
+        if (allow_tail && g.NBB > 1 && rem <= kDiagTailLanes) {
             g.tail_lanes = rem;
             g.NBB -= 1;
         }

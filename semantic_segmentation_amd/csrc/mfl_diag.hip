@@ -390,6 +390,10 @@ struct Loop {
     // the k pixels of a side send to their shared element is summed and added to the gradient planes
     // with one float atomic per lane (64 consecutive floats per wave).  A flagged side splits the sum
     // between the shared and the extra element by the same rule the gather reads them.
+#ifdef MFL_ABL_NO_ATOMIC
+    // timing experiment: the sums are formed, the atomics replaced by a store no launch performs
+    __device__ __forceinline__ void unsafeAtomicAdd(float *p, float v) const { if (v == 1234.5678f) *p = v; }
+#endif
     template <int SA>
     __device__ __forceinline__ void tap_scatter(const float (&w)[KS])
     {
@@ -641,7 +645,11 @@ __device__ __forceinline__ void diag_tail_block(const DiagGeom &g, float *tail_l
 #pragma unroll
         for (int j = 0; j < kTailChan; ++j) {
             const unsigned ys = lp[j] / (unsigned)W, xs = lp[j] - ys * (unsigned)W;
+#ifdef MFL_ABL_NO_TAIL_ATOMIC
+            if constexpr (MODE == 3) acc[j] += wv * qv[j] * (float)(tab[rr[j]] + ys * Wp + xs);
+#else
             if constexpr (MODE == 3) unsafeAtomicAdd(grad_b + tab[rr[j]] + ys * Wp + xs, wv * qv[j]);
+#endif
             else acc[j] = fmaf(wv, in_b[tab[rr[j]] + ys * Wp + xs], acc[j]);
             lp[j] += qL;
             rr[j] += rL;
@@ -794,6 +802,9 @@ diag_kernel(DiagGeom g, int epi_rows, int tail_per_group, const float *__restric
     if constexpr (MODE == 3) {
         // backward: D = dy * x of the workgroup's pixels goes through LDS the other way round (threads
         // load whole pixels, coalesced; lanes pick up their diagonals), chunk by chunk
+        const __amdgpu_buffer_rsrc_t rdy =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(unary + (size_t)img * C * L), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rxc = __builtin_amdgcn_make_buffer_rsrc((void *)(in_b + g.FS), 0, 0x7fffffff, 0x00020000);
         for (int cb0 = 0; cb0 < Cfg::NBR; cb0 += CBR) {
             const int rows = (Cfg::NBR - cb0 < CBR) ? Cfg::NBR - cb0 : CBR;
             const int cnt = rows * Cfg::RUN;
@@ -802,10 +813,16 @@ diag_kernel(DiagGeom g, int epi_rows, int tail_per_group, const float *__restric
                 const bool ok = place(cb0, r, moff, l, cpos);
                 const int br = r / Cfg::RUN, a_rel = r - br * Cfg::RUN;
                 float *dst = lds + br * Cfg::RUNP + a_rel;
-                const float *dy_b = unary + (size_t)img * C * L + l;
-                const float *xc = in_b + g.FS + cpos;
-                for (int c = 0; c < Cfg::CE; ++c)
-                    dst[c * cstride] = (ok && c < C) ? dy_b[(size_t)c * L] * xc[(size_t)c * g.plane] : 0.f;
+                // all loads first (channels past C re-read channel C-1), then the stores
+                float dv[Cfg::CE], xv[Cfg::CE];
+#pragma unroll
+                for (int c = 0; c < Cfg::CE; ++c) {
+                    const int cc = c < C ? c : C - 1;
+                    dv[c] = buf_load(rdy, l * 4, (uint32_t)(cc * L * 4));
+                    xv[c] = buf_load(rxc, cpos * 4, (uint32_t)(cc * g.plane * 4));
+                }
+#pragma unroll
+                for (int c = 0; c < Cfg::CE; ++c) dst[c * cstride] = (ok && c < C) ? dv[c] * xv[c] : 0.f;
             }
             __syncthreads();
 #pragma unroll
