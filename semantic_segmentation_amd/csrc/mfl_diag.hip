@@ -13,6 +13,9 @@
 //                 offsets straight from the table: no per-lane address arithmetic) for k FMAs.
 // Epilogue: the accumulators go through LDS so that threads own whole pixels again (all channels,
 // consecutive lanes = consecutive pixels) for the fused normalise step or the plain product.
+// The backward reuses the machinery transposed: D = dy * x enters through LDS into the accumulator
+// registers, and per (channel, tap) a lane sums what its k pixels send to the shared element and
+// adds it to the gradient planes with one float atomic (tap_scatter).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
