@@ -397,6 +397,11 @@ struct Loop {
     // timing experiment: the sums are formed, the atomics replaced by a store no launch performs
     __device__ __forceinline__ void unsafeAtomicAdd(float *p, float v) const { if (v == 1234.5678f) *p = v; }
 #endif
+    // (lanes whose pixels are all outside the image hold D = 0: they send nothing)
+    __device__ __forceinline__ void scatter_add(float *p, float v) const
+    {
+        if (v != 0.f) unsafeAtomicAdd(p, v);
+    }
     template <int SA>
     __device__ __forceinline__ void tap_scatter(const float (&w)[KS])
     {
@@ -421,11 +426,11 @@ struct Loop {
                         if (n < NA) { if (pA >= n) eA += t; else sA += t; }
                         else { if (pB >= n) eB += t; else sB += t; }
                     }
-                    unsafeAtomicAdd(base + oA, sA);
-                    unsafeAtomicAdd(base + oA + (gap4 >> 2), eA);
+                    scatter_add(base + oA, sA);
+                    scatter_add(base + oA + (gap4 >> 2), eA);
                     if constexpr (SA > 0) {
-                        unsafeAtomicAdd(base + oB, sB);
-                        unsafeAtomicAdd(base + oB + (gap4 >> 2), eB);
+                        scatter_add(base + oB, sB);
+                        scatter_add(base + oB + (gap4 >> 2), eB);
                     }
                 } else {
                     float dA = 0.f, dB = 0.f;
@@ -434,8 +439,8 @@ struct Loop {
                         if (n < NA) dA = fmaf(w[n], st.acc[i][n], dA);
                         else dB = fmaf(w[n], st.acc[i][n], dB);
                     }
-                    unsafeAtomicAdd(base + oA, dA);
-                    if constexpr (SA > 0) unsafeAtomicAdd(base + oB, dB);
+                    scatter_add(base + oA, dA);
+                    if constexpr (SA > 0) scatter_add(base + oB, dB);
                 }
             }
         }
