@@ -2,24 +2,34 @@
 """Throughput of the fused mean-field / local-window path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): 21 labels, 512x512, batch 8 per GPU, 7x7 window, 10
-mean-field iterations with an LxL label-compatibility matrix, fp32.  One "step" is one call of
-mfl_meanfield_forward over the batch (10 iterations); inputs are resident in HBM before the
-timed region.  With N GPUs every rank owns its own 8 images (weak scaling, no collective on the
-data path); the time is the maximum over ranks between two barriers.
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts its own N rank processes
+(python -m torch.distributed.run, 127.0.0.1) before anything touches the GPU; launched under
+torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as usual.
+
+Headline workload (BASELINE.json configs[3], the one the metric and the 60 % target are quoted on):
+19 labels, 1024x2048, global batch 16, 11x11 window, 10 mean-field iterations with an LxL label
+compatibility matrix, fp32.  One "step" is one call of mfl_meanfield_forward over the rank's images
+(10 iterations); inputs are resident in HBM before the timed region.  The global batch of 16 is
+split over the ranks (16 / 8 / 4 / 2 images per GPU at 1 / 2 / 4 / 8 GPUs: strong scaling, no
+collective on the data path); the time is the maximum over ranks between two barriers.
 
 Prints one JSON line: metric = mean-field iter*Mpixel/s over the whole job, plus
-  roofline      the fused step kernel against the HBM roofline: algorithmic bytes per launch
-                ((12*L + 12) B per pixel-iteration) / its average duration measured with HIP events;
-                traffic = memory-side bytes per launch from the committed PMC passes
-  cpu_baseline  the CPU oracle (a port of the reference's arithmetic) timed on this host's cores
-                on a bounded sample of the same workload (rank 0, N = 1 only).
+  roofline       the fused step kernel against the HBM roofline: algorithmic bytes per launch
+                 ((12*L + 12) B per pixel-iteration) / its average duration measured with HIP events on
+                 the launch stream; `valu` is the same launch against the fp32 vector peak;
+                 traffic = memory-side bytes per launch from the committed PMC passes
+  cpu_baseline   the CPU oracle (a port of the reference's arithmetic) timed on this host's cores on a
+                 512x1024 crop of image 0 (rank 0, N = 1 only), median of 5
+  other_configs  short measurements of BASELINE.json configs[1] and configs[4] (N = 1 only) and of
+                 configs[2] (training step: forward, NLL with 255-ignore, backward, one flat all-reduce
+                 of the potential-parameter gradients)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,161 +40,317 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-LABELS, HEIGHT, WIDTH, WINDOW, ITERS, BATCH_PER_GPU = 21, 512, 512, 7, 10, 8
 POS_W, COL_W = -0.004, -0.003
 HBM_PEAK_GBPS = 8000.0
-VALU_PEAK_TFLOPS = 157.0      # fp32 vector peak
-IMAGENET_MEAN = np.array([0.485, 0.456, 0.406], np.float32).reshape(3, 1, 1)
-IMAGENET_STD = np.array([0.229, 0.224, 0.225], np.float32).reshape(3, 1, 1)
+VALU_PEAK_TFLOPS = 157.3      # fp32 vector peak
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+CONFIGS = {
+    "c4": dict(ref="BASELINE.json configs[3]", what="Cityscapes-shaped inference", labels=19, height=1024, width=2048,
+               window=11, iters=10, batch=16),
+    "c2": dict(ref="BASELINE.json configs[1]", what="AdvancedModel inference", labels=21, height=512, width=512,
+               window=7, iters=10, batch=8),
+    "c5": dict(ref="BASELINE.json configs[4]", what="large-label stress", labels=150, height=512, width=512,
+               window=7, iters=10, batch=16),
+    "c3": dict(ref="BASELINE.json configs[2]", what="AdvancedModel training fwd+bwd", labels=21, height=512,
+               width=512, window=7, iters=1, batch=32),
+}
 
 
-def synthetic_image(index):
-    """Unary logits ~ 2*N(0,1) and an ImageNet-normalised U[0,1) image, seeded per global image index."""
-    rng = np.random.default_rng(1234 + index)
-    unary = (2 * rng.standard_normal((LABELS, HEIGHT, WIDTH))).astype(np.float32)
-    img = ((rng.random((3, HEIGHT, WIDTH), dtype=np.float32) - IMAGENET_MEAN) / IMAGENET_STD).astype(np.float32)
-    return unary, img
+def synthetic_image(cfg, index, device):
+    """Unary logits ~ 2*N(0,1) and an ImageNet-normalised U[0,1) image, seeded per GLOBAL image index
+    (so any batch shard regenerates its own images identically), generated on the device."""
+    g = torch.Generator(device=device)
+    g.manual_seed(1234 + index)
+    unary = 2 * torch.randn(cfg["labels"], cfg["height"], cfg["width"], generator=g, device=device)
+    img = torch.rand(3, cfg["height"], cfg["width"], generator=g, device=device)
+    mean = torch.tensor(IMAGENET_MEAN, device=device).view(3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, device=device).view(3, 1, 1)
+    return unary, (img - mean) / std
 
 
-def compat_matrix():
+def compat_matrix(labels):
     rng = np.random.default_rng(99)
-    return ((1 - np.eye(LABELS)) + 0.01 * rng.standard_normal((LABELS, LABELS))).astype(np.float32)
+    return ((1 - np.eye(labels)) + 0.01 * rng.standard_normal((labels, labels))).astype(np.float32)
 
 
-def cpu_baseline():
-    """The oracle on the host cores: 2 images x 10 iterations of the same workload (second call timed)."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, unary0, img0, crop=(512, 1024), repeats=5):
+    """The oracle on the host cores: the mean-field loop of the same workload on a crop of image 0
+    (second-call timing, median of `repeats`)."""
     from oracle import oracle as O
     O.build()
-    sample = 2
-    data = [synthetic_image(i) for i in range(sample)]
-    unary = np.stack([d[0] for d in data])
-    img = np.stack([d[1] for d in data])
-    compat = compat_matrix()
-    O.meanfield_forward(unary[:1], img[:1], POS_W, COL_W, WINDOW, 1, None, None, compat)      # warm-up
-    t0 = time.perf_counter()
-    O.meanfield_forward(unary, img, POS_W, COL_W, WINDOW, ITERS, None, None, compat)
-    dt = time.perf_counter() - t0
-    return {"value": round(ITERS * sample * HEIGHT * WIDTH / 1e6 / dt, 4), "unit": "iter*Mpixel/s",
-            "cores": O.num_threads(), "kind": "port",
-            "sample": f"{sample} of the {BATCH_PER_GPU} images x {ITERS} iterations, C oracle with OpenMP, "
-                      f"{dt:.1f} s"}
+    h, w = min(crop[0], cfg["height"]), min(crop[1], cfg["width"])
+    unary = unary0[:, :h, :w].contiguous().cpu().numpy()[None]
+    img = img0[:, :h, :w].contiguous().cpu().numpy()[None]
+    compat = compat_matrix(cfg["labels"])
+    k, iters = cfg["window"], cfg["iters"]
+    O.meanfield_forward(unary, img, POS_W, COL_W, k, 1, None, None, compat)      # warm-up
+    ts = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        O.meanfield_forward(unary, img, POS_W, COL_W, k, iters, None, None, compat)
+        ts.append(time.perf_counter() - t0)
+    dt = float(np.median(ts))
+    return {"value": round(iters * h * w / 1e6 / dt, 4), "unit": "iter*Mpixel/s", "cores": O.num_threads(),
+            "kind": "port", "cpu_model": cpu_model(), "host_cpus": os.cpu_count(),
+            "sample": f"{h}x{w} crop of image 0, {cfg['labels']} labels, {k}x{k} window, {iters} iterations, "
+                      f"C oracle with OpenMP on {O.num_threads()} threads, median of {repeats} runs = {dt:.2f} s "
+                      f"(total {sum(ts):.0f} s)"}
 
 
-def measured_traffic():
+def measured_traffic(key):
     """Memory-side bytes per launch of the fused step kernel from the committed PMC passes
     (profiles/traffic.json says how they were collected and corrected); None when absent."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            t = json.load(f)
+            t = json.load(f)[key]
         return int(t["traffic_bytes_per_launch"]), t["sources"]
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, TypeError):
         return None, None
+
+
+def self_launch(args):
+    """Start one rank per GPU; nothing in this process has touched the GPU yet."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    if args.only:
+        cmd += ["--only", args.only]
+    if args.backend != "nccl":
+        cmd += ["--backend", args.backend]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+class Job:
+    """Rank, device and the collectives the timing needs."""
+
+    def __init__(self, gpus, backend="nccl"):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != gpus:
+            raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={self.world}")
+        # one GPU per rank; with fewer devices than ranks (a rehearsal of the launcher on a one-GPU box,
+        # --backend gloo) the ranks share devices
+        local_rank %= max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_rank)
+        self.device = torch.device("cuda", local_rank)
+        self.backend = backend
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.device)
+            else:
+                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+
+    def fence(self):
+        torch.cuda.synchronize(self.device)
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(self.device)
+
+    def max_over_ranks(self, seconds):
+        if self.world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.device if self.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.world > 1:
+            dist.destroy_process_group()
+
+
+def event_ms(fn, reps=5):
+    """Median duration of fn() measured with HIP events on torch's current stream (the launch stream)."""
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts))
+
+
+def run_inference(job, key, steps, warmup, with_cpu):
+    """Strong-scaled inference of CONFIGS[key]: returns the fields of one result (rank 0) or None."""
+    import semantic_segmentation_amd as S
+    cfg = CONFIGS[key]
+    L, H, W, k, iters, batch = cfg["labels"], cfg["height"], cfg["width"], cfg["window"], cfg["iters"], cfg["batch"]
+    lo, hi = S.parallel.shard_range(batch, job.rank, job.world)
+    mine = hi - lo
+    dev = job.device
+    data = [synthetic_image(cfg, i, dev) for i in range(lo, hi)]
+    unary = torch.stack([d[0] for d in data])
+    img = torch.stack([d[1] for d in data])
+    del data
+    compat = torch.from_numpy(compat_matrix(L)).to(dev)
+    pw = torch.tensor([POS_W], device=dev)
+    cw = torch.tensor([COL_W], device=dev)
+
+    def step(n_iters=iters):
+        return S.ops.meanfield_forward(unary, img, pw, cw, k, n_iters, None, None, compat)
+
+    out = None
+    for _ in range(warmup):
+        out = step()
+    job.fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    job.fence()
+    elapsed = job.max_over_ranks(time.perf_counter() - t0)
+    assert torch.isfinite(out).all()
+    del out
+
+    # average duration of one fused step launch: (call with `iters` iterations - call with 1 iteration)
+    # / (iters - 1) removes the one-off set-up of a call
+    t_full, t_one = event_ms(step), event_ms(lambda: step(1))
+    launch_ms = (t_full - t_one) / (iters - 1)
+    pixels = mine * H * W
+    bytes_per_launch = (12 * L + 12) * pixels
+    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+    # algorithmic flops per pixel-iteration: gather MACs + weight build + LxL compat + two softmax passes
+    flops_per_launch = (2 * L * k * k + 11 * k * k + 2 * L * L + 8 * L) * pixels
+    tflops = flops_per_launch / (launch_ms * 1e-3) / 1e12
+    if job.rank != 0:
+        return None
+    traffic, traffic_src = measured_traffic(key)
+    res = {
+        "value": round(iters * batch * H * W * steps / 1e6 / elapsed, 2),
+        "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "config": {"workload": f"{cfg['what']}: {L} labels, {H}x{W}, global batch {batch}, {k}x{k} window, "
+                               f"{iters} mean-field iterations, LxL compat ({cfg['ref']})",
+                   "labels": L, "height": H, "width": W, "window": k, "iters": iters, "global_batch": batch,
+                   "batch_per_gpu": mine, "parallelism": f"batch-shard x{job.world}"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                     "traffic_unit": "bytes per launch (PMC, committed passes)", "traffic_source": traffic_src,
+                     "kernel": "fused mean-field step (one launch per iteration over the rank's images)",
+                     "launch_ms": round(launch_ms, 4), "bytes_per_launch": bytes_per_launch,
+                     "bytes_per_pixel_iteration": 12 * L + 12, "pixels_per_launch": pixels,
+                     "valu": {"achieved": round(tflops, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(tflops / VALU_PEAK_TFLOPS, 4)}},
+    }
+    if with_cpu:
+        res["cpu_baseline"] = cpu_baseline(cfg, unary[0], img[0])
+    return res
+
+
+def run_training(job, key, steps, warmup):
+    """CONFIGS[key] as a training step on the rank's shard: forward (mean-field module), NLL with
+    255-ignore (AdvancedModel.py:164, 298), backward, ONE flat all-reduce of the potential-parameter
+    gradients (AdvancedModel.py:298-303 accumulates before optimizer.step())."""
+    import semantic_segmentation_amd as S
+    cfg = CONFIGS[key]
+    L, H, W, k, iters, batch = cfg["labels"], cfg["height"], cfg["width"], cfg["window"], cfg["iters"], cfg["batch"]
+    lo, hi = S.parallel.shard_range(batch, job.rank, job.world)
+    dev = job.device
+    data = [synthetic_image(cfg, i, dev) for i in range(lo, hi)]
+    unary = torch.stack([d[0] for d in data])
+    img = torch.stack([d[1] for d in data])
+    del data
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321 + job.rank)
+    labels = torch.randint(0, L, (hi - lo, H, W), generator=g, device=dev)
+    labels[torch.rand(hi - lo, H, W, generator=g, device=dev) < 0.05] = 255
+    model = S.MeanFieldLocal(H, W, L, k, iters=iters, compat=True).to(dev)
+    with torch.no_grad():
+        model.local_convolution_layer.position_weight.fill_(POS_W)
+        model.local_convolution_layer.color_weight.fill_(COL_W)
+        model.compat.copy_(torch.from_numpy(compat_matrix(L)).to(dev))
+    loss_fn = torch.nn.NLLLoss(ignore_index=255)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        loss = loss_fn(model(unary, img), labels) * ((hi - lo) / batch)
+        loss.backward()
+        S.parallel.allreduce_gradients(model.parameters())
+        return loss
+
+    for _ in range(warmup):
+        step()
+    job.fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    job.fence()
+    elapsed = job.max_over_ranks(time.perf_counter() - t0)
+    assert torch.isfinite(loss).all()
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    assert all(torch.isfinite(gr).all() for gr in grads)
+    if job.rank != 0:
+        return None
+    return {"workload": f"{cfg['what']}: {L} labels, {H}x{W}, global batch {batch}, {k}x{k} window, "
+                        f"{iters} mean-field iteration(s), fwd + NLL(255-ignore) + bwd + flat all-reduce ({cfg['ref']})",
+            "value": round(batch * H * W * steps / 1e6 / elapsed, 2), "unit": "Mpixel/s (fwd+bwd)",
+            "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "batch_per_gpu": hi - lo,
+            "allreduce_floats": int(sum(gr.numel() for gr in grads))}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the default) or gloo (launcher rehearsal)")
+    ap.add_argument("--only", default="", help="run just the headline workload as this config (c2, c4, c5): "
+                                               "profiling aid, no other_configs")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-
-    import semantic_segmentation_amd as S
-
-    # this rank's shard of the global batch: images [rank*8, rank*8 + 8)
-    data = [synthetic_image(rank * BATCH_PER_GPU + i) for i in range(BATCH_PER_GPU)]
-    unary = torch.from_numpy(np.stack([d[0] for d in data])).to(device)
-    img = torch.from_numpy(np.stack([d[1] for d in data])).to(device)
-    compat = torch.from_numpy(compat_matrix()).to(device)
-    pw = torch.tensor([POS_W], device=device)
-    cw = torch.tensor([COL_W], device=device)
-
-    def step(iters=ITERS):
-        return S.ops.meanfield_forward(unary, img, pw, cw, WINDOW, iters, None, None, compat)
-
-    def fence():
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(device)
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(out).all()
-
-    # average duration of one fused step launch, HIP events on the launch stream:
-    # (call with ITERS iterations - call with 1 iteration) / (ITERS - 1) removes the one-off
-    # padding / table set-up of a call.
-    def timed(iters, reps=5):
-        best = []
-        for _ in range(reps):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            step(iters)
-            e1.record()
-            e1.synchronize()
-            best.append(e0.elapsed_time(e1))
-        return float(np.median(best))
-
-    t_full, t_one = timed(ITERS), timed(1)
-    launch_ms = (t_full - t_one) / (ITERS - 1)
-    pixels = BATCH_PER_GPU * HEIGHT * WIDTH
-    bytes_per_launch = (12 * LABELS + 12) * pixels
-    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-    # algorithmic flops per pixel-iteration: gather MACs + weight build + LxL compat + two softmax passes
-    flops_per_launch = (2 * LABELS * WINDOW ** 2 + 11 * WINDOW ** 2 + 2 * LABELS ** 2 + 8 * LABELS) * pixels
-    tflops = flops_per_launch / (launch_ms * 1e-3) / 1e12
-
-    if rank == 0:
-        traffic, traffic_src = measured_traffic()
-        total_pixel_iters = ITERS * BATCH_PER_GPU * world * HEIGHT * WIDTH * args.steps
-        line = {
-            "metric": "mean-field iter*Mpixel/s (node)",
-            "value": round(total_pixel_iters / 1e6 / elapsed, 2),
-            "unit": "iter*Mpixel/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "AdvancedModel inference: 21 labels, 512x512, batch 8 per GPU, 7x7 window, "
-                                   "10 mean-field iterations, LxL compat (BASELINE.json configs[1])",
-                       "labels": LABELS, "height": HEIGHT, "width": WIDTH, "window": WINDOW, "iters": ITERS,
-                       "batch_per_gpu": BATCH_PER_GPU, "global_batch": BATCH_PER_GPU * world,
-                       "parallelism": f"batch-shard x{world}"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "traffic_unit": "bytes per launch (PMC, committed passes)", "traffic_source": traffic_src,
-                         "kernel": "diag_kernel (one fused mean-field step: regular tiles + tail workgroups)", "launch_ms": round(launch_ms, 4),
-                         "bytes_per_launch": bytes_per_launch,
-                         "valu": {"achieved": round(tflops, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(tflops / VALU_PEAK_TFLOPS, 4)}},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+    job = Job(args.gpus, args.backend)
+    head = args.only or "c4"
+    main_res = run_inference(job, head, args.steps, args.warmup, job.world == 1 and not args.no_cpu_baseline)
+    others = {}
+    if not args.only:
+        torch.cuda.empty_cache()
+        r = run_training(job, "c3", steps=5, warmup=2)
+        if r:
+            others["config3_training"] = r
+        if job.world == 1:
+            for key, st, wu in (("c2", 5, 2), ("c5", 2, 1)):
+                torch.cuda.empty_cache()
+                r = run_inference(job, key, st, wu, False)
+                others["config2" if key == "c2" else "config5"] = {
+                    "workload": r["config"]["workload"], "value": r["value"], "unit": "iter*Mpixel/s",
+                    "ms_per_step": r["ms_per_step"], "steps": st, "launch_ms": r["roofline"]["launch_ms"],
+                    "hbm_frac": r["roofline"]["frac"], "valu_frac": r["roofline"]["valu"]["frac"]}
+    if job.rank == 0:
+        line = {"metric": "mean-field iter*Mpixel/s (node)", "value": main_res["value"], "unit": "iter*Mpixel/s",
+                "n_gpus": job.world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": main_res["config"],
+                "roofline": main_res["roofline"]}
+        if "cpu_baseline" in main_res:
+            line["cpu_baseline"] = main_res["cpu_baseline"]
+        if others:
+            line["other_configs"] = others
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    job.close()
 
 
 if __name__ == "__main__":

@@ -524,7 +524,11 @@ int diag_prepare(const DiagGeom &g, const float *x, const float *img, float *x_f
 void diag_lds(const DiagGeom &g, DiagArgs &a)
 {
     const size_t wbytes = 2 * (size_t)g.TB * g.NBR * g.RUNP * 4;
+#ifdef MFL_EXP_NGW
+    const size_t lds = wbytes > 24 * 1024 ? wbytes : 24 * 1024;   // timing experiment: several workgroups per CU
+#else
     const size_t lds = wbytes > 96 * 1024 ? wbytes : 96 * 1024;
+#endif
     // the epilogue passes the workgroup's b rows through LDS in equal chunks (fewest that fit)
     const int max_rows = (int)(lds / ((size_t)g.CH * g.NCS * g.RUNP * 4));
     const int chunks = (g.NBR + max_rows - 1) / max_rows;

@@ -76,6 +76,9 @@ inline bool diag_split(int C, int k, int &CH, int &NCS, int &NGW)
     if (C <= 8) { NCS = 1; NGW = 8; CH = 8; return true; }
     NCS = C <= 22 ? 2 : 3;
     NGW = NCS == 2 ? 4 : 2;
+#ifdef MFL_EXP_NGW
+    if (NCS == 2) NGW = MFL_EXP_NGW;   // timing experiment: smaller workgroups, more of them per CU
+#endif
     const int need = (C + NCS - 1) / NCS;
     CH = need <= 8 ? 8 : need <= 10 ? 10 : 11;
     return true;
@@ -142,7 +145,7 @@ inline int make_diag_geom(DiagGeom &g, int B, int C, int H, int W, int k, int ld
     diag_split(C, k, g.CH, g.NCS, g.NGW);
     g.NGB = (g.NG + g.NGW - 1) / g.NGW;
     g.RUN = g.NGW * k;
-    g.RUNP = g.RUN | 1;
+    g.RUNP = (g.RUN & 1) ? g.RUN + 2 : g.RUN + 1;
     g.NBR = 64 + k - 1;
     g.Lk = (int)(L % k);
     g.FS = diag_front_slack(k);

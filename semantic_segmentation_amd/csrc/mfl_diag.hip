@@ -36,7 +36,7 @@ template <int CH, int KS, int NGW, int NCS>
 struct DiagCfg {
     static constexpr int NT = 64 * NGW * NCS;
     static constexpr int RUN = NGW * KS;
-    static constexpr int RUNP = RUN | 1;
+    static constexpr int RUNP = (RUN & 1) ? RUN + 2 : RUN + 1;
     static constexpr int NBR = 64 + KS - 1;
     static constexpr int NSLOT = NBR * RUN;
     static constexpr int S = (NSLOT + NT - 1) / NT;
@@ -1098,6 +1098,9 @@ int MFL_CAT3(launch_diag_ch, MFL_DIAG_CH, _k, MFL_DIAG_KS)(const DiagArgs &a, in
     } else {
         if (ngw == 4 && ncs == 2) return launch_cfg<CH, KS, 4, 2>(a, mode, st);
         if (ngw == 2 && ncs == 3) return launch_cfg<CH, KS, 2, 3>(a, mode, st);
+#ifdef MFL_EXP_NGW
+        if (ngw == MFL_EXP_NGW && ncs == 2) return launch_cfg<CH, KS, MFL_EXP_NGW, 2>(a, mode, st);
+#endif
     }
     return MFL_ERR_INVALID_ARGUMENT;
 }

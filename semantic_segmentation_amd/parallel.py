@@ -33,7 +33,13 @@ def allreduce_gradients(parameters: Iterable[torch.nn.Parameter], group=None) ->
     if not params or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        # a CPU-side process group (tests, rehearsals): stage the flat buffer through the host
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     offset = 0
     for p in params:
         n = p.numel()

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/../semantic_segmentation_amd/csrc"
 CH=${ABL_CH:-11}; KS=${ABL_KS:-7}
 OTHERS=$(ls build/mfl_gather_*.o build/mfl_diag_*.o | grep -v mfl_diag_ch${CH}_k${KS}.o)
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -DMFL_STAMPS -c -o build/abl_api_stamps.o mfl_api.hip
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -c -o build/abl_api.o mfl_api.hip
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $ABL_API_FLAGS -c -o build/abl_api.o mfl_api.hip
 while [ $# -ge 2 ]; do
   tag=$1; flags=$2; shift 2
   ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -mllvm -simplifycfg-sink-common=false -Wno-unused-function $flags \
