@@ -13,10 +13,12 @@
 // Thread mapping, index map and the incremental decode: mfl_core.h; gather kernels: mfl_gather.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/mfl.h"
 #include "mfl_gather.h"
 #include "mfl_diag_api.h"
+#include "mfl_ring_api.h"
 
 using namespace mfl;
 
@@ -537,6 +539,89 @@ void diag_lds(const DiagGeom &g, DiagArgs &a)
     a.epi_rows = rows;
 }
 
+
+// ---- ring gather path (mfl_ring.hip): the forward operators for images at least 64 + k wide, odd k <= 11 ----
+__global__ void ring_table_kernel(RingGeom r, uint32_t *__restrict__ table)
+{
+    const DiagGeom &g = r.d;
+    const size_t nrec = (size_t)g.NBB * g.NG * r.recs_per_wave * g.NCS;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrec; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % g.NCS);
+        size_t rest = i / g.NCS;
+        const int pos = (int)(rest % r.recs_per_wave);
+        rest /= r.recs_per_wave;
+        const int gamma = (int)(rest % g.NG);
+        const int beta = (int)(rest / g.NG);
+        ring_fill_record(r, beta, gamma, pos, ci, table + i * g.RECW);
+    }
+}
+
+struct RingWorkspace {
+    size_t xp, xp2, ip4, table, wtab, compat, total;
+};
+
+RingWorkspace ring_carve(int op, const RingGeom &r)
+{
+    const DiagGeom &g = r.d;
+    RingWorkspace w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    w.xp = take(diag_padded_floats(g) * 4);
+    if (op == MFL_OP_MEANFIELD_FORWARD) w.xp2 = take(diag_padded_floats(g) * 4);
+    w.ip4 = take(((size_t)g.B * g.plane + 64) * sizeof(F4));
+    w.table = take(ring_table_dwords(r) * 4 + 256);
+    w.wtab = take(ring_weight_floats(r) * 4 + 256);
+    w.compat = take((size_t)(g.CH * g.NCS + 1) * (g.CH * g.NCS + 1) * 4);
+    w.total = off;
+    return w;
+}
+
+bool ring_eligible(int op, int B, int C, int H, int W, int k, RingGeom &r)
+{
+    if (op != MFL_OP_LOCAL_FORWARD && op != MFL_OP_MEANFIELD_FORWARD) return false;
+#ifdef MFL_NO_RING
+    return false;
+#endif
+    if (make_ring_geom(r, B, C, H, W, k) != 0) return false;
+    return true;
+}
+
+int dispatch_ring(const RingArgs &a, int mode, hipStream_t st)
+{
+#define MFL_RING_CASE(CHV, KSV) \
+    if (a.r.d.CH == CHV && a.r.d.k == KSV) return launch_ring_ch##CHV##_k##KSV(a, mode, st);
+    MFL_RING_CASE(8, 3) MFL_RING_CASE(11, 3) MFL_RING_CASE(8, 5) MFL_RING_CASE(11, 5)
+    MFL_RING_CASE(8, 7) MFL_RING_CASE(11, 7) MFL_RING_CASE(8, 9) MFL_RING_CASE(7, 11)
+#undef MFL_RING_CASE
+    return MFL_ERR_INVALID_ARGUMENT;
+}
+
+// Pads x (planes) and img and builds the record table.
+int ring_prepare(const RingGeom &r, const float *x, const float *img, const float *pos_w, const float *col_w, float *x_floats,
+                 F4 *ip4, uint32_t *table, float *wtab, hipStream_t st)
+{
+    const DiagGeom &g = r.d;
+    const size_t n = (size_t)g.B * g.C * g.plane;
+    MFL_CHECK_HIP(hipMemsetAsync(x_floats, 0, (size_t)g.FS * 4, st));
+    hipLaunchKernelGGL(pad_planes_kernel, dim3(pad_rows_grid((size_t)g.B * g.C * g.Hp)), dim3(kThreads), 0, st, x, x_floats + g.FS,
+                       g.B * g.C, g.H, g.W, g.Hp, g.Wp, g.p0);
+    MFL_CHECK_HIP(hipMemsetAsync(x_floats + g.FS + n, 0, (3 * (size_t)g.Wp + 64) * 4, st));
+    const size_t ni = (size_t)g.B * g.plane;
+    hipLaunchKernelGGL(pad_image4_kernel, dim3(grid_for(ni)), dim3(kThreads), 0, st, img, ip4, g.B, g.H, g.W, g.Hp,
+                       g.Wp, g.p0);
+    MFL_CHECK_HIP(hipMemsetAsync(ip4 + ni, 0, 64 * sizeof(F4), st));
+    const size_t nrec = (size_t)g.NBB * g.NG * r.recs_per_wave * g.NCS;
+    const unsigned blocks = (unsigned)((nrec + 255) / 256 < 65535u * 8 ? (nrec + 255) / 256 : 65535u * 8);
+    hipLaunchKernelGGL(ring_table_kernel, dim3(blocks), dim3(256), 0, st, r, table);
+    RingArgs wa{};
+    wa.r = r;
+    wa.ip4 = ip4;
+    wa.pos_w = pos_w;
+    wa.col_w = col_w;
+    wa.wtab_out = wtab;
+    return dispatch_ring(wa, 3, st);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ C ABI
@@ -564,6 +649,19 @@ size_t mfl_workspace_bytes(int op, int B, int C, int H, int W, int k, int iters)
 {
     (void)iters;
     if (op != MFL_OP_LOCAL_FORWARD && op != MFL_OP_LOCAL_BACKWARD && op != MFL_OP_MEANFIELD_FORWARD) return 0;
+    RingGeom rg;
+    if (ring_eligible(op, B, C, H, W, k, rg) && !(op == MFL_OP_MEANFIELD_FORWARD && C > 33)) {
+        // (the local forward takes the ring kernels with an image and the generic ones with a cd tensor)
+        size_t need = ring_carve(op, rg).total;
+        if (op == MFL_OP_LOCAL_FORWARD) {
+            Geom g0;
+            if (make_geom(g0, B, C, H, W, k, 1) == 0) {
+                const size_t generic = carve(op, g0, pick_cc(C)).total;
+                if (generic > need) need = generic;
+            }
+        }
+        return need;
+    }
     DiagGeom dg;
     const bool diag = diag_eligible(op, B, C, H, W, k, dg);
     if (diag && op != MFL_OP_LOCAL_BACKWARD) return diag_carve(op, dg).total;
@@ -592,6 +690,26 @@ int mfl_local_forward(const float *x, const float *img, const float *cd, const f
     int rc = check_common(x, y, B, C, H, W, k);
     if (rc) return rc;
     if (!pos_w || !col_w || (img == nullptr) == (cd == nullptr)) return MFL_ERR_INVALID_ARGUMENT;
+    RingGeom rg;
+    if (img && ring_eligible(MFL_OP_LOCAL_FORWARD, B, C, H, W, k, rg)) {
+        const RingWorkspace ws = ring_carve(MFL_OP_LOCAL_FORWARD, rg);
+        if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
+        char *base = (char *)workspace;
+        hipStream_t st = (hipStream_t)stream;
+        rc = ring_prepare(rg, x, img, pos_w, col_w, (float *)(base + ws.xp), (F4 *)(base + ws.ip4), (uint32_t *)(base + ws.table),
+                          (float *)(base + ws.wtab), st);
+        if (rc) return rc;
+        RingArgs ra{};
+        ra.r = rg;
+        ra.xp = (const float *)(base + ws.xp);
+        ra.ip4 = (const F4 *)(base + ws.ip4);
+        ra.table = (const uint32_t *)(base + ws.table);
+        ra.wtab = (const float *)(base + ws.wtab);
+        ra.pos_w = pos_w;
+        ra.col_w = col_w;
+        ra.y = y;
+        return dispatch_ring(ra, 1, st);
+    }
     DiagGeom dg;
     if (img && diag_eligible(MFL_OP_LOCAL_FORWARD, B, C, H, W, k, dg)) {
         const DiagWorkspace ws = diag_carve(MFL_OP_LOCAL_FORWARD, dg);
@@ -733,6 +851,47 @@ int mfl_meanfield_forward(const float *unary, const float *img, const float *pos
     if (rc) return rc;
     if (!logq || !pos_w || !col_w || iters <= 0 || (affine_w == nullptr) != (affine_b == nullptr))
         return MFL_ERR_INVALID_ARGUMENT;
+    RingGeom rg;
+    if (C <= 33 && ring_eligible(MFL_OP_MEANFIELD_FORWARD, B, C, H, W, k, rg)) {
+        const DiagGeom &g = rg.d;
+        const RingWorkspace ws = ring_carve(MFL_OP_MEANFIELD_FORWARD, rg);
+        if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
+        char *base = (char *)workspace;
+        hipStream_t st = (hipStream_t)stream;
+        float *qa = (float *)(base + ws.xp), *qb = (float *)(base + ws.xp2);
+        rc = ring_prepare(rg, unary, img, pos_w, col_w, qa, (F4 *)(base + ws.ip4), (uint32_t *)(base + ws.table),
+                          (float *)(base + ws.wtab), st);
+        if (rc) return rc;
+        MFL_CHECK_HIP(hipMemsetAsync(qb, 0, diag_padded_floats(g) * 4, st));   // borders of the other buffer
+        RingArgs ra{};
+        ra.r = rg;
+        ra.ip4 = (const F4 *)(base + ws.ip4);
+        ra.table = (const uint32_t *)(base + ws.table);
+        ra.wtab = (const float *)(base + ws.wtab);
+        ra.pos_w = pos_w;
+        ra.col_w = col_w;
+        ra.unary = unary;
+        ra.aw = affine_w;
+        ra.ab = affine_b;
+        if (compat) {
+            float *cpad = (float *)(base + ws.compat);
+            hipLaunchKernelGGL(pad_compat_kernel, dim3(1), dim3(kThreads), 0, st, compat, cpad, C, (g.CH * g.NCS + 1) & ~1);
+            ra.compat = cpad;
+            ra.compat_plain = compat;
+        }
+#ifdef MFL_STAMPS
+        ra.y = (float *)g_stamps;      // diagnostic builds: cycle stamps of the first workgroups
+#endif
+        for (int it = 0; it < iters; ++it) {
+            ra.xp = qa;
+            ra.qp_out = qb;
+            ra.logq = (it == iters - 1) ? logq : nullptr;
+            rc = dispatch_ring(ra, 0, st);
+            if (rc) return rc;
+            float *t = qa; qa = qb; qb = t;
+        }
+        return MFL_OK;
+    }
     DiagGeom dg;
     if (diag_eligible(MFL_OP_MEANFIELD_FORWARD, B, C, H, W, k, dg)) {
         const DiagWorkspace ws = diag_carve(MFL_OP_MEANFIELD_FORWARD, dg);

@@ -25,7 +25,7 @@
 //
 // ---- who computes what ---------------------------------------------------------
 // group      gamma = a0 / k           (C*k groups)
-// b-block    beta: lanes own b = 64*beta + lane - n
+// b-block    beta: lanes own b = BL*beta + lane - n (BL = 64 here)
 // channels are split over NCS waves of CH channels each; a workgroup is NGW consecutive
 // groups x NCS channel splits and shares one table of tap weights in LDS.
 #ifndef MFL_DIAG_H
@@ -44,7 +44,9 @@ struct DiagGeom {
     int Hp, Wp, plane, gap;   // zero-padded plane; gap = Wp - W = k - 1
     int NB;                   // number of b values: ceil(L / CK)
     int NG;                   // groups: C*k
-    int NBB;                  // b-blocks of 64 lanes the diagonal kernels run
+    int BL;                   // b values per block: 64 (diagonal kernels) or 65 - k (stream kernels: the last k - 1
+                              // lanes of a wave only load elements the other lanes need at image-row starts)
+    int NBB;                  // b-blocks the kernels run
     int tail_lanes;           // lanes of one more, nearly empty b-block whose few pixels go to the tail
                               // kernel instead (0: none)
     int NGW, NCS, CH;         // workgroup = NGW groups x NCS channel splits; CH channels per wave
@@ -131,6 +133,7 @@ inline int make_diag_geom(DiagGeom &g, int B, int C, int H, int W, int k, int ld
     g.L = (int)L; g.CK = (int)CK; g.Hp = (int)Hp; g.Wp = (int)Wp; g.plane = (int)plane; g.gap = k - 1;
     g.NB = (int)((L + CK - 1) / CK);
     g.NG = C * k;
+    g.BL = 64;
     g.NBB = (g.NB + k - 1 + 63) / 64;
     g.tail_lanes = 0;
     {
@@ -188,7 +191,7 @@ MFL_HD DiagStep diag_step(const DiagGeom &g, int beta, int gamma, int t, int c)
     const int rho = r0 / g.k, s = r0 - rho * g.k;
     DiagStep st;
     // A: line rho of source pixel lp0 + 64*beta
-    const long long uA = lp0 + 64LL * beta;
+    const long long uA = lp0 + (long long)g.BL * beta;
     const int yA = (int)(uA / g.W);
     st.xA = (int)(uA - (long long)yA * g.W);
     const int cA = rho / g.k, kyA = rho - cA * g.k;
@@ -283,7 +286,7 @@ MFL_HD bool diag_reads_extra(int T, int lane, int n) { return lane - T >= n; }
 // or -1 for a candidate past the end of the image (l >= L).
 MFL_HD int diag_tail_lanes(const DiagGeom &g, int n)
 {
-    const int m = g.NB - 64 * g.NBB + n;
+    const int m = g.NB - g.BL * g.NBB + n;
     return m < 0 ? 0 : (m < g.tail_lanes ? m : g.tail_lanes);
 }
 MFL_HD int diag_tail_per_group(const DiagGeom &g)
@@ -299,7 +302,7 @@ MFL_HD int diag_tail_pixel(const DiagGeom &g, long long idx)
     const int gamma = (int)(idx / per);
     int r = (int)(idx - (long long)gamma * per), n = 0;
     while (r >= diag_tail_lanes(g, n)) r -= diag_tail_lanes(g, n++);
-    const long long a = (long long)gamma * g.k + n, bb = 64LL * g.NBB + r - n;
+    const long long a = (long long)gamma * g.k + n, bb = (long long)g.BL * g.NBB + r - n;
     const long long l = a + bb * g.CK;
     return l < g.L ? (int)l : -1;
 }

@@ -1,0 +1,649 @@
+// Stream gather kernels of the local-window message-passing library (gfx950): the fast path for
+// images at least 64 + k pixels wide.  Ownership map (a thread owns a diagonal of k output pixels that
+// share one element of pad(x) per (channel, tap)): mfl_diag.h; tap stream and table records:
+// mfl_ring.h.  One translation unit per (CH, KS): compile with -DMFL_RING_CH= -DMFL_RING_KS=.
+//
+// One workgroup = NGW consecutive groups x NCS channel splits (one wave each) of one b-block of one
+// image.  In the tap loop every wave is on its own (no workgroup barrier, no LDS traffic).  Per stream
+// tap a wave
+//   - holds the k weights of each lane's pixels in registers, loaded a tap ahead from the weight table
+//     (lane-major, 16 bytes per lane and load: full cache lines); the table is written once per call by
+//     weights_kernel (the weights pd*pos_w + col_w*|I(l) - I(l + tap)|^2 do not change between the
+//     iterations of a call): recomputing them per iteration cost more than half of all cache-line
+//     requests of the step (one 12-byte image load per pixel and tap, in runs of k pixels);
+//   - per channel: k FMAs on the shared elements (A, B) that were loaded during the previous tap,
+//     then the loads of the next tap's (A, B) into the same registers (one coalesced dword per lane
+//     each, scalar offsets straight from the table record: no per-lane address arithmetic).
+// Epilogue: the accumulators go through LDS so that threads own whole pixels again (all channels,
+// consecutive lanes = consecutive pixels) for the fused normalise step or the plain product.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mfl.h"
+#include "mfl_ring_api.h"
+#include "mfl_tail.h"
+
+#if !defined(MFL_RING_CH) || !defined(MFL_RING_KS)
+#error "compile with -DMFL_RING_CH=<channels per wave> -DMFL_RING_KS=<window side>"
+#endif
+
+using namespace mfl;
+
+namespace {
+
+typedef float f3 __attribute__((ext_vector_type(3)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef const uint32_t __attribute__((address_space(4))) *ConstWords;   // scalar loads: the table is never written here
+
+template <int CH, int KS, int NGW, int NCS>
+struct RingCfg {
+    static constexpr int NW = NGW * NCS;
+    static constexpr int NT = 64 * NW;
+    static constexpr int RUN = NGW * KS;
+    static constexpr int RUNP = (RUN & 1) ? RUN + 2 : RUN + 1;   // pitch of the epilogue tile
+    static constexpr int BL = 65 - KS;                            // lanes of a wave that own pixels
+    static constexpr int NBR = BL + KS - 1;                       // b rows of a workgroup's tile (= 64)
+    static constexpr int WQ = (KS + 3) / 4;                       // 16-byte pieces of a lane's k weights
+    static constexpr int RECW = ((2 * CH + (CH + 1) / 2 + 3) / 4) * 4;
+    static constexpr int CE = CH * NCS;
+};
+
+// MFL_ABL_* macros: timing experiments only; they remove one part of the kernel and give wrong results.
+
+// Offsets of one tap (next tap's sides A and B) and the thresholds of one tap, held in scalar registers.
+template <int CH>
+struct Offsets {
+    uint32_t a[CH], b[CH];
+};
+template <int CH>
+struct Thresholds {
+    uint32_t w[(CH + 1) / 2];
+};
+
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, int voff, uint32_t soff)
+{
+#ifdef MFL_ABL_NO_LOADS
+    return __builtin_bit_cast(float, (uint32_t)voff + soff);
+#endif
+#ifdef MFL_ABL_SMALL_WINDOW
+    soff &= MFL_ABL_SMALL_WINDOW;    // timing experiment: every element load inside one small window
+#endif
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, (int)soff, 0));
+}
+
+template <int CH, int KS, int NGW, int NCS>
+struct Loop {
+    using Cfg = RingCfg<CH, KS, NGW, NCS>;
+    static constexpr int RECW = Cfg::RECW;
+
+    float (&acc)[CH][KS];
+    __amdgpu_buffer_rsrc_t rsrc;            // FS floats before the pad(x) planes of the image
+    __amdgpu_buffer_rsrc_t wrsrc;           // this wave's part of the weight table: [position][piece][lane][4]
+    ConstWords recp;                        // record of the current stream position
+    int rec_stride;                         // dwords between consecutive stream positions
+    unsigned long long cols_kx, cols_sa;    // tap columns in stream order and their classes, 4 bits each
+    int gap;
+    int lane, bsrc;                         // bsrc: byte address of lane + gap for the lane permute
+    int pos;                                // stream position
+    Offsets<CH> offn;                       // offsets of the next tap (refills)
+    Thresholds<CH> thr;                     // thresholds of the current tap
+    float a[CH], b[CH];                     // shared elements of the current tap, refilled in place
+#ifdef MFL_STAMPS
+    // diagnostic build only: cycles per tap segment, summed over the taps
+    unsigned long long seg[6], seg_t;
+#define MFL_SEG(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg[i] += t_ - seg_t; seg_t = t_; } while (0)
+#else
+#define MFL_SEG(i) do { } while (0)
+#endif
+
+    __device__ __forceinline__ void load_offsets(ConstWords p)
+    {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { offn.a[c] = p[c]; offn.b[c] = p[CH + c]; }
+    }
+    __device__ __forceinline__ void load_thresholds(ConstWords p)
+    {
+#pragma unroll
+        for (int j = 0; j < (CH + 1) / 2; ++j) thr.w[j] = p[2 * CH + j];
+    }
+
+    // One gather step: pixels n < KS - SA take side A, the others side B.
+    template <int SA, int STEP>
+    __device__ __forceinline__ void step(const float (&w)[KS])
+    {
+        constexpr int NA = KS - SA;
+        const float ea0 = a[STEP], eb0 = b[STEP];
+#ifndef MFL_ABL_NO_FMA
+#pragma unroll
+        for (int n = 0; n < KS; ++n) acc[STEP][n] = fmaf(w[n], n < NA ? ea0 : eb0, acc[STEP][n]);
+#endif
+#ifndef MFL_ABL_NO_CORR
+        const uint32_t t16 = (thr.w[STEP / 2] >> (16 * (STEP & 1))) & 0xffffu;
+        if (t16 != 0x8080u) {
+            // The 64-lane run meets the start of an image row: pixel n of a lane reads the element gap floats
+            // further where lane - T >= n (mfl_diag.h, diag_side).  The FMAs above took the shared element for
+            // every pixel; this adds w[n] * (extra - shared) where it applies.  The extra element of a lane
+            // is the shared element of lane + gap: a lane permute (the lanes that own pixels end gap lanes
+            // before the wave does).  The updates are in-place instructions by construction: a three-address
+            // FMA here makes the compiler copy the step's accumulators on the common path.
+            const float xa = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsrc, __builtin_bit_cast(int, ea0)));
+            const float xb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsrc, __builtin_bit_cast(int, eb0)));
+            const float da = xa - ea0, db = xb - eb0;
+            const int pA = lane - ((int)(t16 & 255u) - 64), pB = lane - ((int)(t16 >> 8) - 64);
+#pragma unroll
+            for (int n = 0; n < KS; ++n) {
+                const float t = (n < NA ? pA : pB) >= n ? w[n] : 0.f;
+                asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[STEP][n]) : "v"(t), "v"(n < NA ? da : db));
+            }
+        }
+#endif
+    }
+
+    template <int SA, int STEP>
+    __device__ __forceinline__ void steps(const float (&w)[KS])
+    {
+        step<SA, STEP>(w);
+#ifndef MFL_ABL_NO_GLOADS
+        // the next tap's elements into the registers this step has just consumed
+        a[STEP] = buf_load(rsrc, lane * 4, offn.a[STEP]);
+        b[STEP] = buf_load(rsrc, lane * 4, offn.b[STEP]);
+#endif
+        if constexpr (STEP + 1 < CH) steps<SA, STEP + 1>(w);
+    }
+
+    // The k weights of the lane's pixels at stream position i (positions past the end repeat the last one).
+    __device__ __forceinline__ void load_weights(float (&w)[KS], int i) const
+    {
+        constexpr int K = KS * KS;
+        const int ic = i < K ? i : K - 1;
+#pragma unroll
+        for (int q = 0; q < Cfg::WQ; ++q) {
+            const f4 v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16, (ic * Cfg::WQ + q) * 1024, 0));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * q + j < KS) w[4 * q + j] = v[j];
+        }
+    }
+
+    // One tap of alignment class SA at stream position `pos` with the weights `w` (loaded a tap ago).
+    template <int SA>
+    __device__ __forceinline__ void tap(float (&w)[KS])
+    {
+        MFL_SEG(5);
+        float wn[KS];
+        load_weights(wn, pos + 1);
+        MFL_SEG(0);
+        steps<SA, 0>(w);
+        MFL_SEG(1);
+        // records of the taps to come, requested well before their first use: thresholds of the next tap,
+        // offsets of the one after it (the stream's last record repeats itself)
+        constexpr int K = KS * KS;
+        recp += rec_stride;
+        load_thresholds(recp);
+        load_offsets(pos + 2 <= K ? recp + rec_stride : recp);
+        MFL_SEG(2);
+#pragma unroll
+        for (int n = 0; n < KS; ++n) w[n] = wn[n];
+        ++pos;
+    }
+
+    // All tap columns of alignment class SA (one unrolled loop body per class: the accumulators are
+    // updated in place through one chain of loops, no two bodies meet in a common successor), then the
+    // next class.
+    template <int SA>
+    __device__ __forceinline__ void classes(int col, float (&w)[KS])
+    {
+        while (col < KS && (int)((cols_sa >> (4 * col)) & 15) == SA) {
+            for (int ky = 0; ky < KS; ++ky) tap<SA>(w);
+            ++col;
+        }
+        if constexpr (SA + 1 < KS) classes<SA + 1>(col, w);
+    }
+
+    // Elements and weights of stream tap 0 requested, then the stream.
+    __device__ __forceinline__ void run()
+    {
+        pos = 0;
+        load_offsets(recp);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            a[c] = buf_load(rsrc, lane * 4, offn.a[c]);
+            b[c] = buf_load(rsrc, lane * 4, offn.b[c]);
+        }
+        load_thresholds(recp);
+        load_offsets(recp + rec_stride);
+        float w[KS];
+        load_weights(w, 0);
+#ifdef MFL_STAMPS
+        for (int i = 0; i < 6; ++i) seg[i] = 0;
+        seg_t = __builtin_amdgcn_s_memtime();
+#endif
+        classes<0>(0, w);
+    }
+};
+
+// Tap (ky, kx) at stream position i.
+__device__ __forceinline__ void stream_tap(const RingGeom &r, int i, int &ky, int &kx)
+{
+    const int col = i / r.d.k;
+    ky = i - col * r.d.k;
+    kx = (int)((r.cols_kx >> (4 * col)) & 15);
+}
+
+// Weight table of a call: w[img][b-block][group][stream position][piece q][lane][4] with
+// w = pd*pos_w + col_w*|I(l) - I(l + tap)|^2 (LocalConvolution.py:84 with the colour distance of
+// AdvancedModel.py:547) for pixel n = 4q + j of the lane.  One wave per (image, b-block, group): per tap its
+// lanes compute the weights of the wave's 64 x k pixels in image order (slot sigma = lane + 64 i is pixel
+// sigma % k of lane sigma / k: consecutive lanes read consecutive pixels), pass them through LDS and
+// write them lane-major, 1 KiB per store instruction.
+template <int KS>
+__global__ void __launch_bounds__(256)
+weights_kernel(RingGeom rg, const F4 *__restrict__ ip4, const float *__restrict__ pos_w, const float *__restrict__ col_w,
+               float *__restrict__ wtab)
+{
+    constexpr int WQ = (KS + 3) / 4, WP = 4 * WQ + 1, K = KS * KS;
+    __shared__ float lds[4][2][64 * WP];
+    const DiagGeom &g = rg.d;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long unit = (long long)blockIdx.x * 4 + wave;          // (image, b-block, group)
+    const long long units = (long long)g.B * g.NBB * g.NG;
+    if (unit >= units) return;
+    const int gamma = (int)(unit % g.NG);
+    const int beta = (int)((unit / g.NG) % g.NBB);
+    const int img = (int)(unit / ((long long)g.NG * g.NBB));
+    const F4 *__restrict__ ip_b = ip4 + (size_t)img * g.plane;
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ip_b, 0, 0x7fffffff, 0x00020000);
+    const float pw = *pos_w, cw = *col_w;
+    const int ctr_off = g.p0 * g.Wp + g.p0;
+    int ioff[KS], place[KS];
+    float cr[KS], cg[KS], cb[KS];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+        const int sigma = lane + 64 * i;
+        const int owner = sigma / KS, n = sigma - owner * KS;
+        const int aa = gamma * KS + n, bb = g.BL * beta + owner - n;
+        const long long l = (long long)aa + (long long)bb * g.CK;
+        const bool valid = owner < g.BL && bb >= 0 && l < g.L;
+        const int lc = valid ? (int)l : 0;
+        const int yy = lc / g.W, xx = lc - yy * g.W;
+        const int ibase = yy * g.Wp + xx;
+        ioff[i] = ibase * 16;
+        place[i] = owner * WP + n;
+        const F4 c = ip_b[ibase + ctr_off];
+        cr[i] = c.x; cg[i] = c.y; cb[i] = c.z;
+    }
+    float *out = wtab + (size_t)unit * K * (WQ * 256);
+    for (int pos = 0; pos < K; ++pos) {
+        int ky, kx;
+        stream_tap(rg, pos, ky, kx);
+        const int toff = ky * g.Wp + kx;
+        const int dy = ky - g.p0, dx = kx - g.p0;
+        const float pdw = (float)(dy * dy + dx * dx) * pw;
+        float *wt = lds[wave][pos & 1];
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            const f3 nb = __builtin_bit_cast(f3, __builtin_amdgcn_raw_buffer_load_b96(irsrc, ioff[i], toff * 16, 0));
+            const float d0 = cr[i] - nb.x, d1 = cg[i] - nb.y, d2 = cb[i] - nb.z;
+            const float cd = fmaf(d2, d2, fmaf(d1, d1, d0 * d0));
+            wt[place[i]] = fmaf(cd, cw, pdw);
+        }
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < WQ; ++q) {
+            f4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = 4 * q + j < KS ? wt[lane * WP + 4 * q + j] : 0.f;
+            *reinterpret_cast<f4 *>(out + ((size_t)(pos * WQ + q) * 64 + lane) * 4) = v;
+        }
+        // (two buffers: the next tap writes the other one, the one after it meets this wave's reads of
+        // this tap long done; LDS operations of a wave complete in order)
+    }
+}
+
+// MODE 0: fused mean-field update   MODE 1: y = x * window sums   MODE 2: y = window sums
+template <int CH, int KS, int NGW, int NCS, int MODE>
+__global__ void __launch_bounds__(64 * NGW * NCS)
+ring_kernel(RingGeom rg, int lds_floats, int tail_per_group, const float *__restrict__ xp, const F4 *__restrict__ ip4,
+            const uint32_t *__restrict__ table, const float *__restrict__ wtab, const float *__restrict__ pos_w, const float *__restrict__ col_w,
+            const float *__restrict__ unary, const float *__restrict__ aw, const float *__restrict__ ab,
+            const float *__restrict__ compat, const float *__restrict__ compat_plain, float *__restrict__ logq,
+            float *__restrict__ qp_out, float *__restrict__ y_out)
+{
+    using Cfg = RingCfg<CH, KS, NGW, NCS>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const DiagGeom &g = rg.d;
+    {
+        // workgroups past the regular tiles: the pixels of a nearly empty last b-block
+        const int regular = g.NBB * g.NGB * g.B;
+        if ((int)blockIdx.x >= regular) {
+            diag_tail_block<MODE>(g, lds, (int)blockIdx.x - regular, Cfg::NW, tail_per_group, xp, ip4, pos_w, col_w, unary, aw, ab,
+                                  compat_plain, logq, qp_out, y_out);
+            return;
+        }
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gi = wave % NGW, ci = wave / NGW;
+    // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2); with the image index
+    // fastest, image i of a batch of 8 stays on XCD i % 8.
+    const int img = blockIdx.x % g.B;
+    const int tile = blockIdx.x / g.B;
+    const int gb = tile % g.NGB, beta = tile / g.NGB;
+    const int gamma = gb * NGW + gi;
+    const bool live = gamma < g.NG;
+    const int C = g.C, CK = g.CK, L = g.L, W = g.W, Wp = g.Wp;
+
+    const size_t img_off = (size_t)img * C * g.plane;
+    const float *in_b = xp + img_off;                 // FS floats before the image's padded planes
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in_b, 0, 0x7fffffff, 0x00020000);
+    float acc[CH][KS];
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+#pragma unroll
+        for (int n = 0; n < KS; ++n) acc[i][n] = 0.f;
+
+    const int gamma_t = live ? gamma : g.NG - 1;      // a wave without a group works on the last group (results dropped)
+    const size_t wunit = ((size_t)img * g.NBB + beta) * g.NG + gamma_t;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(wtab + wunit * (size_t)(KS * KS) * (Cfg::WQ * 256)), 0, 0x7fffffff, 0x00020000);
+    Loop<CH, KS, NGW, NCS> loop{acc, rsrc, wrsrc,
+                                (ConstWords)(uintptr_t)(table + ring_record_index(rg, beta, gamma_t, 0, ci)),
+                                g.NCS * g.RECW, rg.cols_kx, rg.cols_sa, g.gap, lane, ((lane + g.gap) & 63) * 4, 0, {}, {}, {}, {}};
+#ifdef MFL_STAMPS
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
+    loop.run();
+#ifdef MFL_STAMPS
+    unsigned long long *dbg = reinterpret_cast<unsigned long long *>(y_out);
+    const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+#endif
+    __syncthreads();
+
+    // ---- epilogue: accumulators -> LDS [channel][b_rel][a_rel], then one pixel per thread ----
+    const int CBR0 = lds_floats / (Cfg::CE * Cfg::RUNP);
+    const int chunks = (Cfg::NBR + CBR0 - 1) / CBR0;
+    const int CBR = (Cfg::NBR + chunks - 1) / chunks;
+    const int cstride = CBR * Cfg::RUNP;
+    // pixel r of the chunk starting at b row cb0: LDS place, output pixel l and centre position in
+    // the padded plane; false for the places of the tile that are no pixel of this workgroup
+    auto place = [&](int cb0, int r, int &moff, int &l, int &cpos) {
+        const int rows = (Cfg::NBR - cb0 < CBR) ? Cfg::NBR - cb0 : CBR;
+        const int br = r / Cfg::RUN, a_rel = r - br * Cfg::RUN;
+        const int b_rel = cb0 + br;
+        const int n = a_rel % KS;
+        const int owner = b_rel - (KS - 1) + n;
+        const int aa = gb * Cfg::RUN + a_rel, bb = Cfg::BL * beta + b_rel - (KS - 1);
+        const long long l64 = (long long)aa + (long long)bb * CK;
+        const bool ok = br < rows && owner >= 0 && owner < Cfg::BL && bb >= 0 && aa < CK && l64 < L;
+        l = ok ? (int)l64 : 0;
+        const int yy = l / W, xx = l - yy * W;
+        cpos = (yy + g.p0) * Wp + xx + g.p0;
+        moff = ok ? br * Cfg::RUNP + a_rel : 0;
+        return ok;
+    };
+    // accumulators of the b rows [cb0, cb0 + CBR) -> LDS.  The tile has room for all CH * NCS channel
+    // rows, so the padded channels of the last split are written without a guard and never read.
+    auto transpose = [&](int cb0) {
+        if (live && lane < Cfg::BL) {
+#pragma unroll
+            for (int n = 0; n < KS; ++n) {
+                const int br = lane - n + KS - 1 - cb0;
+                if (br >= 0 && br < CBR) {
+                    float *dst = lds + (ci * CH * CBR + br) * Cfg::RUNP + gi * KS + n;
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) dst[i * cstride] = acc[i][n];
+                }
+            }
+        }
+    };
+    if constexpr (MODE == 1 || MODE == 2) {
+        for (int cb0 = 0; cb0 < Cfg::NBR; cb0 += CBR) {
+            transpose(cb0);
+            __syncthreads();
+            const int rows = (Cfg::NBR - cb0 < CBR) ? Cfg::NBR - cb0 : CBR;
+            const int cnt = rows * Cfg::RUN;
+            for (int r = tid; r < cnt; r += Cfg::NT) {
+                int moff, l, cpos;
+                if (!place(cb0, r, moff, l, cpos)) continue;
+                const float *msg = lds + moff;
+                const float *qc = in_b + g.FS + cpos;
+                float *y_b = y_out + (size_t)img * C * L + l;
+                for (int c = 0; c < C; ++c)
+                    y_b[(size_t)c * L] = MODE == 1 ? msg[c * cstride] * qc[(size_t)c * g.plane] : msg[c * cstride];
+            }
+            __syncthreads();
+        }
+    } else {
+        // One pixel per thread and pass.  The pixel's unary and Q values do not depend on the gather,
+        // so the passes are software pipelined: the loads of the next pass (possibly of the next
+        // chunk) are issued before the arithmetic of the current one.  Channel planes are reached with
+        // scalar offsets (buffer addressing): no per-channel address arithmetic in the vector unit.
+        // Channels past C read channel C-1 and are neutralised by value (unary -inf; their messages are
+        // finite and meet zero columns of the padded label matrix), so that all loads issue back to back.
+        constexpr int CE = Cfg::CE, CE2 = (CE + 1) & ~1;
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)(in_b + g.FS), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ru =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(unary + (size_t)img * C * L), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rqo =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(qp_out + img_off + g.FS), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rlq = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)((logq ? logq : qp_out) + (size_t)img * C * L), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t raw = __builtin_amdgcn_make_buffer_rsrc((void *)(aw ? aw : unary), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rab = __builtin_amdgcn_make_buffer_rsrc((void *)(ab ? ab : unary), 0, 0x7fffffff, 0x00020000);
+        const int plane4 = g.plane * 4, L4 = L * 4;
+        auto bload = [](__amdgpu_buffer_rsrc_t r, int voff, uint32_t soff) {
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, (int)soff, 0));
+        };
+        struct Pixel {
+            bool ok;
+            int moff, l, cpos;
+            float u[CE], qv[CE];
+        };
+        auto fetch = [&](int cb0, int it, Pixel &x) {
+            x.ok = place(cb0, tid + it * Cfg::NT, x.moff, x.l, x.cpos);
+#pragma unroll
+            for (int c = 0; c < CE; ++c) {
+                const int cc = c < C ? c : C - 1;
+                x.qv[c] = bload(rq, x.cpos * 4, (uint32_t)(cc * plane4));
+                x.u[c] = bload(ru, x.l * 4, (uint32_t)(cc * L4));
+            }
+        };
+        // (wide channel capacities have no registers to spare for a second set of loaded values)
+        constexpr bool kPrefetch = CE <= 24;
+        Pixel nxt;
+        if constexpr (kPrefetch) fetch(0, 0, nxt);
+        for (int cb0 = 0; cb0 < Cfg::NBR; cb0 += CBR) {
+            transpose(cb0);
+            __syncthreads();
+            const int rows = (Cfg::NBR - cb0 < CBR) ? Cfg::NBR - cb0 : CBR;
+#ifdef MFL_ABL_NO_EPI
+            const int nit = 0;
+#else
+            const int nit = (rows * Cfg::RUN + Cfg::NT - 1) / Cfg::NT;
+#endif
+            for (int it = 0; it < nit; ++it) {
+                Pixel cur;
+                if constexpr (kPrefetch) {
+                    cur = nxt;
+                    // the pass after this one (after the last one: this one again, loaded and dropped,
+                    // which keeps the loop free of branches around loads)
+                    const bool more = it + 1 < nit, chunk = cb0 + CBR < Cfg::NBR;
+                    fetch(more ? cb0 : (chunk ? cb0 + CBR : cb0), more ? it + 1 : (chunk ? 0 : it), nxt);
+                } else {
+                    fetch(cb0, it, cur);
+                }
+                const float *msg = lds + cur.moff;
+                const int l = cur.l, cpos = cur.cpos;
+                float m[CE], u[CE];
+#pragma unroll
+                for (int c = 0; c < CE; ++c) {
+                    const int cc = c < C ? c : C - 1;
+                    m[c] = msg[cc * cstride];
+                    u[c] = cur.u[c];
+                }
+                if (aw) {
+#pragma unroll
+                    for (int c = 0; c < CE; ++c) {
+                        const int cc = c < C ? c : C - 1;
+                        const float av = bload(raw, l * 4, (uint32_t)(cc * L4));
+                        const float bv = bload(rab, l * 4, (uint32_t)(cc * L4));
+                        m[c] = fmaf(av, m[c] * cur.qv[c], bv);
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CE; ++c) m[c] *= cur.qv[c];
+                }
+                float mu = -INFINITY;
+#pragma unroll
+                for (int c = 0; c < CE; ++c) {
+                    // (channel splits leave at most 10 padded channels: only those need the test)
+                    if (c >= CE - 10) u[c] = c < C ? u[c] : -INFINITY;
+                    mu = fmaxf(mu, u[c]);
+                }
+                float su = 0.f;
+#pragma unroll
+                for (int c = 0; c < CE; ++c) su += __expf(u[c] - mu);
+                const float lse_u = mu + __logf(su);
+                // compat: the transposed, zero-padded CE2 x CE2 copy of the C x C matrix, so that a
+                // pair of output channels is one packed FMA with a scalar register pair
+                f2 pv[CE2 / 2];
+                if (compat) {
+                    const f2 *ct = reinterpret_cast<const f2 *>(compat);
+#pragma unroll
+                    for (int cp = 0; cp < CE2 / 2; ++cp) pv[cp] = f2{0.f, 0.f};
+#pragma unroll
+                    for (int c2 = 0; c2 < CE; ++c2)
+#pragma unroll
+                        for (int cp = 0; cp < CE2 / 2; ++cp)
+                            pv[cp] = __builtin_elementwise_fma(ct[c2 * (CE2 / 2) + cp], f2{m[c2], m[c2]}, pv[cp]);
+                } else {
+#pragma unroll
+                    for (int cp = 0; cp < CE2 / 2; ++cp) pv[cp] = f2{m[2 * cp], 2 * cp + 1 < CE ? m[2 * cp + 1] : 0.f};
+                }
+                float mv = -INFINITY;
+#pragma unroll
+                for (int c = 0; c < CE; ++c) {
+                    u[c] = (u[c] - lse_u) - pv[c / 2][c & 1];
+                    mv = fmaxf(mv, u[c]);
+                }
+                // Q_{t+1} = exp(u - mv) / sum: the exponentials of the sum are reused for the output
+                float sv = 0.f;
+#pragma unroll
+                for (int c = 0; c < CE; ++c) {
+                    u[c] -= mv;
+                    m[c] = __expf(u[c]);
+                    sv += m[c];
+                }
+                const float rsv = 1.f / sv;
+                if (cur.ok) {
+#pragma unroll
+                    for (int c = 0; c < CE; ++c)
+                        if (c < C) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, m[c] * rsv), rqo, cpos * 4, c * plane4, 0);
+                    if (logq) {
+                        const float lsv = __logf(sv);
+#pragma unroll
+                        for (int c = 0; c < CE; ++c)
+                            if (c < C) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, u[c] - lsv), rlq, l * 4, c * L4, 0);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+#ifdef MFL_STAMPS
+    if (MODE == 0 && dbg && blockIdx.x < 512 && lane == 0) {
+        unsigned long long *d = dbg + ((size_t)blockIdx.x * Cfg::NW + wave) * 16;
+        for (int i = 0; i < 6; ++i) d[i] = loop.seg[i];
+        d[6] = t_loop - t_begin;
+        d[7] = __builtin_amdgcn_s_memtime() - t_loop;
+        d[8] = t_begin;
+    }
+#endif
+}
+
+template <int CH, int KS, int NGW, int NCS>
+size_t lds_bytes_cfg(const RingGeom &r)
+{
+    using Cfg = RingCfg<CH, KS, NGW, NCS>;
+    const DiagGeom &g = r.d;
+    size_t need = 0;
+    // the epilogue tile: at least ceil(NBR / 3) b rows of all channels per pass
+    const size_t epi = (size_t)Cfg::CE * Cfg::RUNP * ((Cfg::NBR + 2) / 3) * 4;
+    if (epi > need) need = epi;
+    const size_t tail = ((size_t)g.CK + (size_t)Cfg::NW * kTailPix * (g.K + 2 * g.C)) * 4;
+    if (g.tail_lanes && tail > need) need = tail;
+    return (need + 255) & ~(size_t)255;
+}
+
+template <int CH, int KS, int NGW, int NCS>
+int launch_cfg(const RingArgs &a, int mode, hipStream_t st)
+{
+    using Cfg = RingCfg<CH, KS, NGW, NCS>;
+    const DiagGeom &g = a.r.d;
+    if (g.CH != CH || g.k != KS || g.NGW != NGW || g.NCS != NCS || g.RECW != Cfg::RECW)
+        return MFL_ERR_INVALID_ARGUMENT;
+    // regular tiles, then the workgroups of the tail pixels (one wave per chunk of kTailPix pixels)
+    const int tail_per_group = g.tail_lanes ? diag_tail_per_group(g) : 0;
+    const long long tail_waves = (long long)g.B * g.NG * ((tail_per_group + kTailPix - 1) / kTailPix);
+    const long long tail_blocks = (tail_waves + Cfg::NW - 1) / Cfg::NW;
+    const long long blocks = (long long)g.NBB * g.NGB * g.B + tail_blocks;
+    if (blocks >= (1LL << 31)) return MFL_ERR_TOO_LARGE;
+    const size_t lds = lds_bytes_cfg<CH, KS, NGW, NCS>(a.r);
+    if (lds > 160 * 1024) return MFL_ERR_INVALID_ARGUMENT;
+    const dim3 grid((unsigned)blocks);
+    auto go = [&](auto kern) -> int {
+        // the attribute is a property of the kernel: set once per process and kernel (racing first calls
+        // set the same value)
+        static bool raised = false;
+        if (!raised) {
+            const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            raised = true;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), lds, st, a.r, (int)(lds / 4), tail_per_group, a.xp, a.ip4, a.table, a.wtab, a.pos_w,
+                           a.col_w, a.unary, a.aw, a.ab, a.compat, a.compat_plain, a.logq, a.qp_out, a.y);
+        return 0;
+    };
+    if (mode == 3) {
+        // the weight table of the call
+        const long long units = (long long)g.B * g.NBB * g.NG;
+        hipLaunchKernelGGL(weights_kernel<KS>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, a.r, a.ip4, a.pos_w, a.col_w,
+                           a.wtab_out);
+        return (int)hipGetLastError();
+    }
+    int rc;
+    switch (mode) {
+    case 0: rc = go(ring_kernel<CH, KS, NGW, NCS, 0>); break;
+    case 1: rc = go(ring_kernel<CH, KS, NGW, NCS, 1>); break;
+    case 2: rc = go(ring_kernel<CH, KS, NGW, NCS, 2>); break;
+    default: return MFL_ERR_INVALID_ARGUMENT;
+    }
+    if (rc) return rc;
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+namespace mfl {
+
+#define MFL_CAT4_(a, b, c, d) a##b##c##d
+#define MFL_CAT4(a, b, c, d) MFL_CAT4_(a, b, c, d)
+
+int MFL_CAT4(launch_ring_ch, MFL_RING_CH, _k, MFL_RING_KS)(const RingArgs &a, int mode, hipStream_t st)
+{
+    constexpr int CH = MFL_RING_CH, KS = MFL_RING_KS;
+    const int ngw = a.r.d.NGW, ncs = a.r.d.NCS;
+    if constexpr (KS <= 7) {
+        if (ngw == 4 && ncs == 1) return launch_cfg<CH, KS, 4, 1>(a, mode, st);
+    }
+    if (ngw == 2 && ncs == 2) return launch_cfg<CH, KS, 2, 2>(a, mode, st);
+    if (ngw == 1 && ncs == 3) return launch_cfg<CH, KS, 1, 3>(a, mode, st);
+    if constexpr (KS >= 9) {
+        if (ngw == 1 && ncs == 4) return launch_cfg<CH, KS, 1, 4>(a, mode, st);
+    }
+    return MFL_ERR_INVALID_ARGUMENT;
+}
+
+}  // namespace mfl

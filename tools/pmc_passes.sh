@@ -5,6 +5,6 @@ IFS='|'
 for set in $SETS; do
   unset IFS
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
-  timeout -s KILL 120 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmc_$tag -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/pmc_$tag.log 2>&1 || { echo "pass $tag failed"; tail -3 $R/gpurun_out/pmc_$tag.log; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmc_$tag -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --only ${PMC_CFG:-c4} > $R/gpurun_out/pmc_$tag.log 2>&1 || { echo "pass $tag failed"; tail -3 $R/gpurun_out/pmc_$tag.log; exit 1; }
   echo "pass $tag ok"
 done
