@@ -464,6 +464,16 @@ __global__ void pad_compat_kernel(const float *__restrict__ src, float *__restri
     }
 }
 
+// dst[c2][c] = src[c][c2] zero-padded to 32 x 32 (no matrix: the identity): the layout the stream
+// kernels' fused epilogue loads its matrix operand from
+__global__ void ring_compat_kernel(const float *__restrict__ src, float *__restrict__ dst, int C)
+{
+    for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) {
+        const int c2 = i / 32, c = i - c2 * 32;
+        dst[i] = (c < C && c2 < C) ? (src ? src[c * C + c2] : (c == c2 ? 1.f : 0.f)) : 0.f;
+    }
+}
+
 size_t diag_padded_floats(const DiagGeom &g) { return (size_t)g.FS + (size_t)g.B * g.C * g.plane + 3 * (size_t)g.Wp + 64; }
 
 DiagWorkspace diag_carve(int op, const DiagGeom &g)
@@ -571,7 +581,7 @@ RingWorkspace ring_carve(int op, const RingGeom &r)
     w.ip4 = take(((size_t)g.B * g.plane + 64) * sizeof(F4));
     w.table = take(ring_table_dwords(r) * 4 + 256);
     w.wtab = take(ring_weight_floats(r) * 4 + 256);
-    w.compat = take((size_t)(g.CH * g.NCS + 1) * (g.CH * g.NCS + 1) * 4);
+    w.compat = take(32 * 32 * 4);
     w.total = off;
     return w;
 }
@@ -583,6 +593,15 @@ bool ring_eligible(int op, int B, int C, int H, int W, int k, RingGeom &r)
     return false;
 #endif
     if (make_ring_geom(r, B, C, H, W, k) != 0) return false;
+#ifdef MFL_EXPERIMENTS
+    if (const char *e = getenv("MFL_RING_NGW")) {        // timing experiments: another workgroup width
+        DiagGeom &g = r.d;
+        g.NGW = atoi(e);
+        g.NGB = (g.NG + g.NGW - 1) / g.NGW;
+        g.RUN = g.NGW * g.k;
+        g.RUNP = (g.RUN & 1) ? g.RUN + 2 : g.RUN + 1;
+    }
+#endif
     return true;
 }
 
@@ -590,8 +609,7 @@ int dispatch_ring(const RingArgs &a, int mode, hipStream_t st)
 {
 #define MFL_RING_CASE(CHV, KSV) \
     if (a.r.d.CH == CHV && a.r.d.k == KSV) return launch_ring_ch##CHV##_k##KSV(a, mode, st);
-    MFL_RING_CASE(8, 3) MFL_RING_CASE(11, 3) MFL_RING_CASE(8, 5) MFL_RING_CASE(11, 5)
-    MFL_RING_CASE(8, 7) MFL_RING_CASE(11, 7) MFL_RING_CASE(8, 9) MFL_RING_CASE(7, 11)
+    MFL_RING_CASE(8, 9) MFL_RING_CASE(7, 11)
 #undef MFL_RING_CASE
     return MFL_ERR_INVALID_ARGUMENT;
 }
@@ -650,7 +668,7 @@ size_t mfl_workspace_bytes(int op, int B, int C, int H, int W, int k, int iters)
     (void)iters;
     if (op != MFL_OP_LOCAL_FORWARD && op != MFL_OP_LOCAL_BACKWARD && op != MFL_OP_MEANFIELD_FORWARD) return 0;
     RingGeom rg;
-    if (ring_eligible(op, B, C, H, W, k, rg) && !(op == MFL_OP_MEANFIELD_FORWARD && C > 33)) {
+    if (ring_eligible(op, B, C, H, W, k, rg) && !(op == MFL_OP_MEANFIELD_FORWARD && C > 32)) {
         // (the local forward takes the ring kernels with an image and the generic ones with a cd tensor)
         size_t need = ring_carve(op, rg).total;
         if (op == MFL_OP_LOCAL_FORWARD) {
@@ -852,7 +870,7 @@ int mfl_meanfield_forward(const float *unary, const float *img, const float *pos
     if (!logq || !pos_w || !col_w || iters <= 0 || (affine_w == nullptr) != (affine_b == nullptr))
         return MFL_ERR_INVALID_ARGUMENT;
     RingGeom rg;
-    if (C <= 33 && ring_eligible(MFL_OP_MEANFIELD_FORWARD, B, C, H, W, k, rg)) {
+    if (C <= 32 && ring_eligible(MFL_OP_MEANFIELD_FORWARD, B, C, H, W, k, rg)) {
         const DiagGeom &g = rg.d;
         const RingWorkspace ws = ring_carve(MFL_OP_MEANFIELD_FORWARD, rg);
         if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
@@ -873,9 +891,9 @@ int mfl_meanfield_forward(const float *unary, const float *img, const float *pos
         ra.unary = unary;
         ra.aw = affine_w;
         ra.ab = affine_b;
-        if (compat) {
+        {
             float *cpad = (float *)(base + ws.compat);
-            hipLaunchKernelGGL(pad_compat_kernel, dim3(1), dim3(kThreads), 0, st, compat, cpad, C, (g.CH * g.NCS + 1) & ~1);
+            hipLaunchKernelGGL(ring_compat_kernel, dim3(1), dim3(kThreads), 0, st, compat, cpad, C);
             ra.compat = cpad;
             ra.compat_plain = compat;
         }

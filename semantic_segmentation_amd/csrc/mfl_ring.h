@@ -45,22 +45,19 @@ struct RingGeom {
 // per group, NGW groups per workgroup (about four waves per workgroup).
 inline bool ring_split(int C, int k, int &CH, int &NCS, int &NGW)
 {
-    int chmax;
-    if (k <= 7) chmax = 11;
-    else if (k == 9) chmax = 8;
-    else chmax = 7;
-    NCS = (C + chmax - 1) / chmax;
-    if (k >= 9 && NCS < 2) NCS = 2;          // wide windows: the weight phase needs at least two waves per group
-    if (NCS > 4 || (k <= 7 && NCS > 3)) return false;
-    const int need = (C + NCS - 1) / NCS;
-    CH = k <= 7 ? (need <= 8 ? 8 : 11) : chmax;
-    NGW = NCS == 1 ? 4 : NCS == 2 ? 2 : 1;
+    CH = k == 9 ? 8 : 7;                     // CH * k accumulators per lane: 72 and 77
+    NCS = (C + CH - 1) / CH;
+    if (NCS < 2) NCS = 2;                    // (a workgroup has at least four waves)
+    if (NCS > 4) return false;
+    NGW = NCS == 4 ? 1 : 2;
     return true;
 }
 
+// The stream kernels are built for the wide windows (9 x 9, 11 x 11); measured on 21 labels, 512 x 512,
+// 7 x 7, the diagonal kernels of mfl_diag.hip are as fast per step and need no weight table.
 inline bool ring_supported(int C, int H, int W, int k)
 {
-    if (!(k == 3 || k == 5 || k == 7 || k == 9 || k == 11)) return false;
+    if (!(k == 9 || k == 11)) return false;
     if (W < 64 + k || W >= 16384) return false;
     const long long CK = (long long)C * k * k, L = (long long)H * W;
     if (L < 4 * CK) return false;

@@ -29,6 +29,22 @@
 
 using namespace mfl;
 
+// cache policy of the streamed operands (weight table, unary, outputs): 2 = non-temporal
+#ifndef MFL_NT_W
+#define MFL_NT_W 0
+#endif
+#ifndef MFL_NT_U
+#define MFL_NT_U 0
+#endif
+#ifndef MFL_NT_ST
+#define MFL_NT_ST 0
+#endif
+
+// waves per SIMD the fused step kernel is compiled for
+#ifndef MFL_M0_WAVES
+#define MFL_M0_WAVES 2
+#endif
+
 namespace {
 
 typedef float f3 __attribute__((ext_vector_type(3)));
@@ -156,9 +172,13 @@ struct Loop {
     {
         constexpr int K = KS * KS;
         const int ic = i < K ? i : K - 1;
+#ifdef MFL_ABL_NO_WLOADS
+        for (int n = 0; n < KS; ++n) w[n] = (float)(ic + n);
+        return;
+#endif
 #pragma unroll
         for (int q = 0; q < Cfg::WQ; ++q) {
-            const f4 v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16, (ic * Cfg::WQ + q) * 1024, 0));
+            const f4 v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16, (ic * Cfg::WQ + q) * 1024, MFL_NT_W));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (4 * q + j < KS) w[4 * q + j] = v[j];
@@ -170,20 +190,34 @@ struct Loop {
     __device__ __forceinline__ void tap(float (&w)[KS])
     {
         MFL_SEG(5);
+        // requested now, used from the end of this tap on: the weights and thresholds of the next tap, the
+        // element offsets of the tap after it (the stream's last record repeats itself)
+        constexpr int K = KS * KS;
         float wn[KS];
         load_weights(wn, pos + 1);
+#ifdef MFL_ABL_NO_RECORDS
+        ConstWords rec1 = recp;
+#else
+        ConstWords rec1 = recp + rec_stride;
+#endif
+        Thresholds<CH> thr1;
+        Offsets<CH> off2;
+#pragma unroll
+        for (int j = 0; j < (CH + 1) / 2; ++j) thr1.w[j] = rec1[2 * CH + j];
+        {
+            ConstWords rec2 = pos + 2 <= K ? rec1 + rec_stride : rec1;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) { off2.a[c] = rec2[c]; off2.b[c] = rec2[CH + c]; }
+        }
         MFL_SEG(0);
         steps<SA, 0>(w);
         MFL_SEG(1);
-        // records of the taps to come, requested well before their first use: thresholds of the next tap,
-        // offsets of the one after it (the stream's last record repeats itself)
-        constexpr int K = KS * KS;
-        recp += rec_stride;
-        load_thresholds(recp);
-        load_offsets(pos + 2 <= K ? recp + rec_stride : recp);
-        MFL_SEG(2);
+        recp = rec1;
+        thr = thr1;
+        offn = off2;
 #pragma unroll
         for (int n = 0; n < KS; ++n) w[n] = wn[n];
+        MFL_SEG(2);
         ++pos;
     }
 
@@ -303,7 +337,7 @@ weights_kernel(RingGeom rg, const F4 *__restrict__ ip4, const float *__restrict_
 
 // MODE 0: fused mean-field update   MODE 1: y = x * window sums   MODE 2: y = window sums
 template <int CH, int KS, int NGW, int NCS, int MODE>
-__global__ void __launch_bounds__(64 * NGW * NCS)
+__global__ void __launch_bounds__(64 * NGW * NCS) __attribute__((amdgpu_waves_per_eu(MODE == 0 ? MFL_M0_WAVES : 4)))
 ring_kernel(RingGeom rg, int lds_floats, int tail_per_group, const float *__restrict__ xp, const F4 *__restrict__ ip4,
             const uint32_t *__restrict__ table, const float *__restrict__ wtab, const float *__restrict__ pos_w, const float *__restrict__ col_w,
             const float *__restrict__ unary, const float *__restrict__ aw, const float *__restrict__ ab,
@@ -361,9 +395,8 @@ ring_kernel(RingGeom rg, int lds_floats, int tail_per_group, const float *__rest
     __syncthreads();
 
     // ---- epilogue: accumulators -> LDS [channel][b_rel][a_rel], then one pixel per thread ----
-    const int CBR0 = lds_floats / (Cfg::CE * Cfg::RUNP);
-    const int chunks = (Cfg::NBR + CBR0 - 1) / CBR0;
-    const int CBR = (Cfg::NBR + chunks - 1) / chunks;
+    constexpr int CBR = Cfg::NT / Cfg::RUN;          // b rows per chunk: one pixel per thread
+    static_assert(CBR >= 1, "a workgroup's threads cover at least one b row of its tile");
     const int cstride = CBR * Cfg::RUNP;
     // pixel r of the chunk starting at b row cb0: LDS place, output pixel l and centre position in
     // the padded plane; false for the places of the tile that are no pixel of this workgroup
@@ -415,146 +448,157 @@ ring_kernel(RingGeom rg, int lds_floats, int tail_per_group, const float *__rest
             __syncthreads();
         }
     } else {
-        // One pixel per thread and pass.  The pixel's unary and Q values do not depend on the gather,
-        // so the passes are software pipelined: the loads of the next pass (possibly of the next
-        // chunk) are issued before the arithmetic of the current one.  Channel planes are reached with
-        // scalar offsets (buffer addressing): no per-channel address arithmetic in the vector unit.
-        // Channels past C read channel C-1 and are neutralised by value (unary -inf; their messages are
-        // finite and meet zero columns of the padded label matrix), so that all loads issue back to back.
-        constexpr int CE = Cfg::CE, CE2 = (CE + 1) & ~1;
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)(in_b + g.FS), 0, 0x7fffffff, 0x00020000);
-        const __amdgpu_buffer_rsrc_t ru =
-            __builtin_amdgcn_make_buffer_rsrc((void *)(unary + (size_t)img * C * L), 0, 0x7fffffff, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rqo =
-            __builtin_amdgcn_make_buffer_rsrc((void *)(qp_out + img_off + g.FS), 0, 0x7fffffff, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rlq = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)((logq ? logq : qp_out) + (size_t)img * C * L), 0, 0x7fffffff, 0x00020000);
-        const __amdgpu_buffer_rsrc_t raw = __builtin_amdgcn_make_buffer_rsrc((void *)(aw ? aw : unary), 0, 0x7fffffff, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rab = __builtin_amdgcn_make_buffer_rsrc((void *)(ab ? ab : unary), 0, 0x7fffffff, 0x00020000);
+        // Two lanes per pixel: lane (p, h) = (lane & 31, lane >> 5) of a wave works on pixel p of the
+        // wave's 32 pixels of a pass.  The label-compatibility product pv[c] = sum_c2 compat[c][c2] * m[c2]
+        // is one chain of v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate) per pass:
+        //   A (rows = output channels)  lane holds ct[2j + h][lane & 31] for k-step j: the 32 x 32
+        //                               transposed, zero-padded matrix, in registers for the whole epilogue
+        //   B (columns = pixels)        lane holds m[p][2j + h] = msg * Q (input channels 2j + h)
+        //   D                           register v of lane (p, h) = pv[p][8 (v / 4) + 4 h + v % 4]
+        // so a lane normalises the output channels {8 g + 4 h + r} of its pixel and the two lanes of a
+        // pixel exchange the maxima and sums of the two softmaxes.  All loads and stores are buffer
+        // accesses whose range check (offset >= C planes) drops the channels past C: loads return 0.
+        constexpr int CE = Cfg::CE;
+        constexpr int KJ = CE >= 32 ? 16 : (CE + 1) / 2;            // k-steps (input channels 2j, 2j + 1)
+        constexpr int NV = CE >= 32 ? 16 : 4 * ((CE + 7) / 8);      // D registers in use
+        typedef float f16v __attribute__((ext_vector_type(16)));
+        const int p = lane & 31, h = lane >> 5;
         const int plane4 = g.plane * 4, L4 = L * 4;
-        auto bload = [](__amdgpu_buffer_rsrc_t r, int voff, uint32_t soff) {
-            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, (int)soff, 0));
+        const uint32_t oob = 0x80000000u;
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)(in_b + g.FS), 0, C * plane4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ru =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(unary + (size_t)img * C * L), 0, C * L4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rqo =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(qp_out + img_off + g.FS), 0, C * plane4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rlq =
+            __builtin_amdgcn_make_buffer_rsrc((void *)((logq ? logq : qp_out) + (size_t)img * C * L), 0, C * L4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t raw = __builtin_amdgcn_make_buffer_rsrc((void *)(aw ? aw : unary), 0, C * L4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rab = __builtin_amdgcn_make_buffer_rsrc((void *)(ab ? ab : unary), 0, C * L4, 0x00020000);
+        auto bload = [](__amdgpu_buffer_rsrc_t r, uint32_t voff) {
+#ifdef MFL_ABL_EPI_NOLOAD
+            return __builtin_bit_cast(float, voff & 0x3fffffffu);
+#endif
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0));
         };
-        struct Pixel {
-            bool ok;
-            int moff, l, cpos;
-            float u[CE], qv[CE];
+        auto other_half = [&](float v) {
+            return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, v)));
         };
-        auto fetch = [&](int cb0, int it, Pixel &x) {
-            x.ok = place(cb0, tid + it * Cfg::NT, x.moff, x.l, x.cpos);
+        float am[KJ];
 #pragma unroll
-            for (int c = 0; c < CE; ++c) {
-                const int cc = c < C ? c : C - 1;
-                x.qv[c] = bload(rq, x.cpos * 4, (uint32_t)(cc * plane4));
-                x.u[c] = bload(ru, x.l * 4, (uint32_t)(cc * L4));
-            }
-        };
-        // (wide channel capacities have no registers to spare for a second set of loaded values)
-        constexpr bool kPrefetch = CE <= 24;
-        Pixel nxt;
-        if constexpr (kPrefetch) fetch(0, 0, nxt);
+        for (int j = 0; j < KJ; ++j) am[j] = compat[(2 * j + h) * 32 + p];
+        // output channels of this lane that exist: bit v
+        uint32_t vmask = 0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) vmask |= (uint32_t)(8 * (v / 4) + 4 * h + (v % 4) < C) << v;
+#ifdef MFL_STAMPS
+        unsigned long long es[24];
+        int esn = 0;
+#define MFL_ES() do { if (esn < 24) es[esn++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MFL_ES() do { } while (0)
+#endif
         for (int cb0 = 0; cb0 < Cfg::NBR; cb0 += CBR) {
+            MFL_ES();
             transpose(cb0);
+            MFL_ES();
             __syncthreads();
+            MFL_ES();
             const int rows = (Cfg::NBR - cb0 < CBR) ? Cfg::NBR - cb0 : CBR;
 #ifdef MFL_ABL_NO_EPI
             const int nit = 0;
 #else
-            const int nit = (rows * Cfg::RUN + Cfg::NT - 1) / Cfg::NT;
+            const int nit = (rows * Cfg::RUN + 32 * Cfg::NW - 1) / (32 * Cfg::NW);
 #endif
             for (int it = 0; it < nit; ++it) {
-                Pixel cur;
-                if constexpr (kPrefetch) {
-                    cur = nxt;
-                    // the pass after this one (after the last one: this one again, loaded and dropped,
-                    // which keeps the loop free of branches around loads)
-                    const bool more = it + 1 < nit, chunk = cb0 + CBR < Cfg::NBR;
-                    fetch(more ? cb0 : (chunk ? cb0 + CBR : cb0), more ? it + 1 : (chunk ? 0 : it), nxt);
-                } else {
-                    fetch(cb0, it, cur);
-                }
-                const float *msg = lds + cur.moff;
-                const int l = cur.l, cpos = cur.cpos;
-                float m[CE], u[CE];
+                int moff, l, cpos;
+                const bool ok = place(cb0, (it * Cfg::NW + wave) * 32 + p, moff, l, cpos);
+                const uint32_t vq = (uint32_t)(cpos * 4 + h * plane4), vu = (uint32_t)(l * 4 + 4 * h * L4);
+                float m[KJ], u[NV];
 #pragma unroll
-                for (int c = 0; c < CE; ++c) {
-                    const int cc = c < C ? c : C - 1;
-                    m[c] = msg[cc * cstride];
-                    u[c] = cur.u[c];
+                for (int j = 0; j < KJ; ++j) m[j] = bload(rq, vq + (uint32_t)(2 * j * plane4));
+#pragma unroll
+                for (int v = 0; v < NV; ++v) u[v] = bload(ru, vu + (uint32_t)((8 * (v / 4) + (v % 4)) * L4));
+                {
+                    const float *msg = lds + moff;
+#pragma unroll
+                    for (int j = 0; j < KJ; ++j) {
+                        // (the row of a channel past the tile: any row, its Q factor is 0)
+                        const int row = 2 * j + 1 < CE ? 2 * j + h : (2 * j < CE ? 2 * j : 0);
+                        m[j] *= msg[row * cstride];
+                    }
                 }
                 if (aw) {
+                    const uint32_t va = (uint32_t)(l * 4 + h * L4);
 #pragma unroll
-                    for (int c = 0; c < CE; ++c) {
-                        const int cc = c < C ? c : C - 1;
-                        const float av = bload(raw, l * 4, (uint32_t)(cc * L4));
-                        const float bv = bload(rab, l * 4, (uint32_t)(cc * L4));
-                        m[c] = fmaf(av, m[c] * cur.qv[c], bv);
-                    }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < CE; ++c) m[c] *= cur.qv[c];
+                    for (int j = 0; j < KJ; ++j)
+                        m[j] = fmaf(bload(raw, va + (uint32_t)(2 * j * L4)), m[j], bload(rab, va + (uint32_t)(2 * j * L4)));
                 }
+                f16v d;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) d[v] = 0.f;
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) d = __builtin_amdgcn_mfma_f32_32x32x2f32(am[j], m[j], d, 0, 0, 0);
                 float mu = -INFINITY;
 #pragma unroll
-                for (int c = 0; c < CE; ++c) {
-                    // (channel splits leave at most 10 padded channels: only those need the test)
-                    if (c >= CE - 10) u[c] = c < C ? u[c] : -INFINITY;
-                    mu = fmaxf(mu, u[c]);
+                for (int v = 0; v < NV; ++v) {
+                    u[v] = (vmask >> v) & 1 ? u[v] : -INFINITY;
+                    mu = fmaxf(mu, u[v]);
                 }
+                mu = fmaxf(mu, other_half(mu));
                 float su = 0.f;
 #pragma unroll
-                for (int c = 0; c < CE; ++c) su += __expf(u[c] - mu);
+                for (int v = 0; v < NV; ++v) su += __expf(u[v] - mu);
+                su += other_half(su);
                 const float lse_u = mu + __logf(su);
-                // compat: the transposed, zero-padded CE2 x CE2 copy of the C x C matrix, so that a
-                // pair of output channels is one packed FMA with a scalar register pair
-                f2 pv[CE2 / 2];
-                if (compat) {
-                    const f2 *ct = reinterpret_cast<const f2 *>(compat);
-#pragma unroll
-                    for (int cp = 0; cp < CE2 / 2; ++cp) pv[cp] = f2{0.f, 0.f};
-#pragma unroll
-                    for (int c2 = 0; c2 < CE; ++c2)
-#pragma unroll
-                        for (int cp = 0; cp < CE2 / 2; ++cp)
-                            pv[cp] = __builtin_elementwise_fma(ct[c2 * (CE2 / 2) + cp], f2{m[c2], m[c2]}, pv[cp]);
-                } else {
-#pragma unroll
-                    for (int cp = 0; cp < CE2 / 2; ++cp) pv[cp] = f2{m[2 * cp], 2 * cp + 1 < CE ? m[2 * cp + 1] : 0.f};
-                }
                 float mv = -INFINITY;
 #pragma unroll
-                for (int c = 0; c < CE; ++c) {
-                    u[c] = (u[c] - lse_u) - pv[c / 2][c & 1];
-                    mv = fmaxf(mv, u[c]);
+                for (int v = 0; v < NV; ++v) {
+                    u[v] = (u[v] - lse_u) - d[v];
+                    mv = fmaxf(mv, u[v]);
                 }
+                mv = fmaxf(mv, other_half(mv));
                 // Q_{t+1} = exp(u - mv) / sum: the exponentials of the sum are reused for the output
-                float sv = 0.f;
+                float e[NV], sv = 0.f;
 #pragma unroll
-                for (int c = 0; c < CE; ++c) {
-                    u[c] -= mv;
-                    m[c] = __expf(u[c]);
-                    sv += m[c];
+                for (int v = 0; v < NV; ++v) {
+                    u[v] -= mv;
+                    e[v] = __expf(u[v]);
+                    sv += e[v];
                 }
+                sv += other_half(sv);
                 const float rsv = 1.f / sv;
-                if (cur.ok) {
+#ifdef MFL_ABL_EPI_NOSTORE
+                const uint32_t sq = rsv == 12345.f ? (uint32_t)(cpos * 4 + 4 * h * plane4) : oob;
+#else
+                const uint32_t sq = ok ? (uint32_t)(cpos * 4 + 4 * h * plane4) : oob;
+#endif
 #pragma unroll
-                    for (int c = 0; c < CE; ++c)
-                        if (c < C) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, m[c] * rsv), rqo, cpos * 4, c * plane4, 0);
-                    if (logq) {
-                        const float lsv = __logf(sv);
+                for (int v = 0; v < NV; ++v)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, e[v] * rsv), rqo,
+                                                          (int)(sq + (uint32_t)((8 * (v / 4) + (v % 4)) * plane4)), 0, 0);
+                if (logq) {
+                    const float lsv = __logf(sv);
+                    const uint32_t sl = ok ? vu : oob;
 #pragma unroll
-                        for (int c = 0; c < CE; ++c)
-                            if (c < C) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, u[c] - lsv), rlq, l * 4, c * L4, 0);
-                    }
+                    for (int v = 0; v < NV; ++v)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, u[v] - lsv), rlq,
+                                                              (int)(sl + (uint32_t)((8 * (v / 4) + (v % 4)) * L4)), 0, 0);
                 }
             }
+            MFL_ES();
             __syncthreads();
         }
+        MFL_ES();
+#ifdef MFL_STAMPS
+        if (dbg && blockIdx.x < 512 && lane == 0) {
+            unsigned long long *dd = dbg + ((size_t)blockIdx.x * Cfg::NW + wave) * 48;
+            for (int i = 0; i < 24; ++i) dd[16 + i] = i < esn ? es[i] - t_loop : 0;
+        }
+#endif
     }
 #ifdef MFL_STAMPS
     if (MODE == 0 && dbg && blockIdx.x < 512 && lane == 0) {
-        unsigned long long *d = dbg + ((size_t)blockIdx.x * Cfg::NW + wave) * 16;
+        unsigned long long *d = dbg + ((size_t)blockIdx.x * Cfg::NW + wave) * 48;
         for (int i = 0; i < 6; ++i) d[i] = loop.seg[i];
         d[6] = t_loop - t_begin;
         d[7] = __builtin_amdgcn_s_memtime() - t_loop;
@@ -569,8 +613,8 @@ size_t lds_bytes_cfg(const RingGeom &r)
     using Cfg = RingCfg<CH, KS, NGW, NCS>;
     const DiagGeom &g = r.d;
     size_t need = 0;
-    // the epilogue tile: at least ceil(NBR / 3) b rows of all channels per pass
-    const size_t epi = (size_t)Cfg::CE * Cfg::RUNP * ((Cfg::NBR + 2) / 3) * 4;
+    // the epilogue tile: as many b rows of all channels as give every thread one pixel per chunk
+    const size_t epi = (size_t)Cfg::CE * Cfg::RUNP * (Cfg::NT / Cfg::RUN) * 4;
     if (epi > need) need = epi;
     const size_t tail = ((size_t)g.CK + (size_t)Cfg::NW * kTailPix * (g.K + 2 * g.C)) * 4;
     if (g.tail_lanes && tail > need) need = tail;
@@ -635,14 +679,13 @@ int MFL_CAT4(launch_ring_ch, MFL_RING_CH, _k, MFL_RING_KS)(const RingArgs &a, in
 {
     constexpr int CH = MFL_RING_CH, KS = MFL_RING_KS;
     const int ngw = a.r.d.NGW, ncs = a.r.d.NCS;
-    if constexpr (KS <= 7) {
-        if (ngw == 4 && ncs == 1) return launch_cfg<CH, KS, 4, 1>(a, mode, st);
-    }
     if (ngw == 2 && ncs == 2) return launch_cfg<CH, KS, 2, 2>(a, mode, st);
+    if (ngw == 2 && ncs == 3) return launch_cfg<CH, KS, 2, 3>(a, mode, st);
+    if (ngw == 1 && ncs == 4) return launch_cfg<CH, KS, 1, 4>(a, mode, st);
+#ifdef MFL_EXPERIMENTS
     if (ngw == 1 && ncs == 3) return launch_cfg<CH, KS, 1, 3>(a, mode, st);
-    if constexpr (KS >= 9) {
-        if (ngw == 1 && ncs == 4) return launch_cfg<CH, KS, 1, 4>(a, mode, st);
-    }
+    if (ngw == 4 && ncs == 2) return launch_cfg<CH, KS, 4, 2>(a, mode, st);
+#endif
     return MFL_ERR_INVALID_ARGUMENT;
 }
 

@@ -25,12 +25,6 @@ struct RingArgs {
 };
 
 #define MFL_DECLARE_RING(CHV, KSV) int launch_ring_ch##CHV##_k##KSV(const RingArgs &a, int mode, hipStream_t st);
-MFL_DECLARE_RING(8, 3)
-MFL_DECLARE_RING(11, 3)
-MFL_DECLARE_RING(8, 5)
-MFL_DECLARE_RING(11, 5)
-MFL_DECLARE_RING(8, 7)
-MFL_DECLARE_RING(11, 7)
 MFL_DECLARE_RING(8, 9)
 MFL_DECLARE_RING(7, 11)
 

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Builds experiment variants of the library: libmfl_<tag>.so = the regular objects with the C-ABI unit
-# and one ring kernel unit (EXP_CH x EXP_KS, default 11 x 7) rebuilt with extra flags.
+# and one ring kernel unit (EXP_CH x EXP_KS, default 7 x 11) rebuilt with extra flags.
 # usage: tools/exp_build.sh tag "-DFLAG ..." [tag flags ...]
 cd "$(dirname "$0")/../semantic_segmentation_amd/csrc"
-CH=${EXP_CH:-11}; KS=${EXP_KS:-7}
+CH=${EXP_CH:-7}; KS=${EXP_KS:-11}
 OTHERS=$(ls build/mfl_gather_*.o build/mfl_diag_*.o build/mfl_ring_*.o | grep -v mfl_ring_${CH}_${KS}.o)
 CC="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function"
 while [ $# -ge 2 ]; do

@@ -13,14 +13,14 @@ unary = torch.from_numpy((2 * rng.standard_normal((B, C, H, W))).astype(np.float
 img = torch.from_numpy(rng.standard_normal((B, 3, H, W)).astype(np.float32)).cuda()
 compat = torch.from_numpy((1 - np.eye(C)).astype(np.float32)).cuda()
 pw = torch.tensor([-0.004], device="cuda"); cw = torch.tensor([-0.003], device="cuda")
-dbg = torch.zeros(512 * NW * 16, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(512 * NW * 48, dtype=torch.int64, device="cuda")
 S.ops.meanfield_forward(unary, img, pw, cw, k, 2, None, None, compat)
 torch.cuda.synchronize()
 _lib.lib.mfl_debug_stamps.argtypes = [ctypes.c_void_p]
 _lib.lib.mfl_debug_stamps(ctypes.c_void_p(dbg.data_ptr()))
 S.ops.meanfield_forward(unary, img, pw, cw, k, 1, None, None, compat)
 torch.cuda.synchronize()
-d = dbg.cpu().numpy().reshape(512 * NW, 16).astype(np.float64)
+d = dbg.cpu().numpy().reshape(512 * NW, 48).astype(np.float64)
 d = d[d[:, 6] > 0]
 names = ["head (weights read, record, image loads issued, slot 0 ready)", "gather steps", "image wait", "weight store + lgkm",
          "barrier", "between taps", "whole loop", "epilogue"]
@@ -28,3 +28,6 @@ K = k * k
 for i, nm in enumerate(names):
     print(f"{nm:62s} median {np.median(d[:, i]):10.0f} cycles  per tap {np.median(d[:, i]) / K:8.1f}")
 print("waves", len(d), " start spread (cycles)", np.ptp(d[:, 8]))
+es = d[:, 16:40]
+print("epilogue stamps (x10 ns after loop end; per chunk: start, transposed, barrier passed, pass done):")
+print(np.array2string(np.median(es, axis=0), precision=0, max_line_width=150))
