@@ -47,6 +47,10 @@ extern "C" {
 #define MFL_ERR_INVALID_ARGUMENT (-1) /* null pointer, non-positive size, unsupported combination */
 #define MFL_ERR_WORKSPACE (-2)        /* workspace missing or smaller than mfl_workspace_bytes() */
 #define MFL_ERR_TOO_LARGE (-3)        /* a 32-bit index inside the kernels would overflow */
+#define MFL_ERR_SCRATCH_LIMIT (-4)    /* mfl_meanfield_forward_noalloc: needs more than MFL_NOALLOC_SCRATCH_BYTES */
+
+/* size of the library's built-in scratch buffer (one per GPU, held until the process ends) */
+#define MFL_NOALLOC_SCRATCH_BYTES (64u << 20)
 
 /* operations for mfl_workspace_bytes() */
 #define MFL_OP_LOCAL_FORWARD 1
@@ -133,6 +137,24 @@ int mfl_meanfield_forward(const float *unary, const float *img, const float *pos
                           const float *affine_w, const float *affine_b, const float *compat, float *logq, int B,
                           int C, int H, int W, int k, int iters, void *workspace, size_t workspace_bytes,
                           mfl_stream_t stream);
+
+/*
+ * mfl_meanfield_forward without a workspace argument, for callers that cannot
+ * allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.
+ * The scratch memory is a buffer of MFL_NOALLOC_SCRATCH_BYTES built into the
+ * library's device image; the call allocates and frees nothing.  Problems with
+ * mfl_workspace_bytes(MFL_OP_MEANFIELD_FORWARD, ...) above that size are rejected
+ * with MFL_ERR_SCRATCH_LIMIT (64 MiB holds one 21-label 512x512 image with a
+ * 7x7 window).  All calls on one GPU share that GPU's buffer: calls that overlap
+ * in time on one GPU (different streams or threads) race; serialise them.  The
+ * first call on a device looks up the buffer's address (set-up; do it once
+ * before capturing a graph).  Same arguments, results and return codes as
+ * mfl_meanfield_forward otherwise.
+ */
+int mfl_meanfield_forward_noalloc(const float *unary, const float *img, const float *pos_w, const float *col_w,
+                                  const float *affine_w, const float *affine_b, const float *compat, float *logq,
+                                  int B, int C, int H, int W, int k, int iters, mfl_stream_t stream);
 
 /*
  * labels[b][y][x] = argmax_c logq[b][c][y][x] (first maximum wins, as

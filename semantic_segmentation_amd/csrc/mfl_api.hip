@@ -12,6 +12,7 @@
 //
 // Thread mapping, index map and the incremental decode: mfl_core.h; gather kernels: mfl_gather.hip.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -642,6 +643,35 @@ int ring_prepare(const RingGeom &r, const float *x, const float *img, const floa
 
 }  // namespace
 
+// ---- built-in scratch of mfl_meanfield_forward_noalloc --------------------------------------------
+// Part of the library's device image: every GPU the library runs on holds its own copy, at its own
+// address, until the process ends.  `scratch` below is a host-side stand-in for the symbol, not a device
+// address: host code only ever uses the pointer hipGetSymbolAddress returned for the current device.
+static __device__ __align__(256) unsigned char scratch[MFL_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+
+constexpr int kMaxDevices = 64;
+std::atomic<void *> g_scratch_ptr[kMaxDevices];
+
+// Address of the current device's copy of `scratch` (looked up once per device, with that device current).
+int scratch_pointer(void **out)
+{
+    int dev = -1;
+    MFL_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return MFL_ERR_INVALID_ARGUMENT;
+    void *p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!p) {
+        MFL_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return MFL_ERR_INVALID_ARGUMENT;
+        g_scratch_ptr[dev].store(p, std::memory_order_release);   // (racing first calls store the same address)
+    }
+    *out = p;
+    return MFL_OK;
+}
+
+}  // namespace
+
 // ------------------------------------------------------------------ C ABI
 
 extern "C" {
@@ -659,6 +689,7 @@ const char *mfl_error_string(int code)
     case MFL_ERR_INVALID_ARGUMENT: return "mfl: invalid argument";
     case MFL_ERR_WORKSPACE: return "mfl: workspace missing or too small";
     case MFL_ERR_TOO_LARGE: return "mfl: problem too large for 32-bit kernel indexing";
+    case MFL_ERR_SCRATCH_LIMIT: return "mfl: problem needs more scratch than the library's built-in buffer (MFL_NOALLOC_SCRATCH_BYTES)";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "mfl: unknown error";
     }
 }
@@ -990,6 +1021,19 @@ int mfl_meanfield_forward(const float *unary, const float *img, const float *pos
         float *t = qa; qa = qb; qb = t;
     }
     return MFL_OK;
+}
+
+int mfl_meanfield_forward_noalloc(const float *unary, const float *img, const float *pos_w, const float *col_w,
+                                  const float *affine_w, const float *affine_b, const float *compat, float *logq,
+                                  int B, int C, int H, int W, int k, int iters, mfl_stream_t stream)
+{
+    const size_t need = mfl_workspace_bytes(MFL_OP_MEANFIELD_FORWARD, B, C, H, W, k, iters);
+    if (need > (size_t)MFL_NOALLOC_SCRATCH_BYTES) return MFL_ERR_SCRATCH_LIMIT;
+    void *ptr = nullptr;
+    const int rc = scratch_pointer(&ptr);
+    if (rc) return rc;
+    return mfl_meanfield_forward(unary, img, pos_w, col_w, affine_w, affine_b, compat, logq, B, C, H, W, k, iters, ptr,
+                                 (size_t)MFL_NOALLOC_SCRATCH_BYTES, stream);
 }
 
 int mfl_argmax_labels(const float *logq, unsigned char *labels, int B, int C, int H, int W, mfl_stream_t stream)
