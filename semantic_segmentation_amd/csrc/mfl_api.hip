@@ -981,6 +981,8 @@ int mfl_meanfield_forward(const float *unary, const float *img, const float *pos
         return MFL_OK;
     }
     const bool fused = C <= 32;
+    // the label transform of the unfused path stages 64 pixels x C messages in LDS (160 KB per workgroup)
+    if (!fused && (affine_w || compat) && (size_t)C * 64 * 4 > 160 * 1024) return MFL_ERR_INVALID_ARGUMENT;
     Geom g;
     int cc;
     bool tab_lds;
@@ -1010,6 +1012,12 @@ int mfl_meanfield_forward(const float *unary, const float *img, const float *pos
             rc = dispatch_local_forward(cc, ga, msg, st);
             if (rc) return rc;
             if (affine_w || compat) {
+                static bool raised = false;     // more than the default 64 KB of dynamic LDS past 256 labels
+                if (!raised) {
+                    MFL_CHECK_HIP(hipFuncSetAttribute((const void *)label_transform_kernel,
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    raised = true;
+                }
                 hipLaunchKernelGGL(label_transform_kernel, dim3((unsigned)((npix + 63) / 64)), dim3(kThreads),
                                    (size_t)C * 64 * 4, st, msg, affine_w, affine_b, compat, msg, B, C, H, W);
             }

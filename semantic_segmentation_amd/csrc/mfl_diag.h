@@ -129,6 +129,9 @@ inline int make_diag_geom(DiagGeom &g, int B, int C, int H, int W, int k, int ld
     const long long K = (long long)k * k, L = (long long)H * W, CK = (long long)C * K;
     const long long Hp = (long long)H + k - 1, Wp = (long long)W + k - 1, plane = Hp * Wp;
     if (L >= (1LL << 30) || (C * plane + 4 * Wp + 256) * 4 >= (1LL << 31)) return -3;
+    // the 16-byte pixels of the padded image are reached through 32-bit byte offsets as well (few channels,
+    // very large images: the planes pass the check above and the image does not)
+    if ((plane + (long long)k * Wp + 64) * 16 >= (1LL << 31)) return -3;
     g.B = B; g.C = C; g.H = H; g.W = W; g.k = k; g.K = (int)K; g.p0 = k / 2;
     g.L = (int)L; g.CK = (int)CK; g.Hp = (int)Hp; g.Wp = (int)Wp; g.plane = (int)plane; g.gap = k - 1;
     g.NB = (int)((L + CK - 1) / CK);

@@ -212,13 +212,23 @@ __device__ __forceinline__ uint32_t rec_word(uint32_t recv, int j)
 #define MFL_CORR_IN(I, N) [w##N] "v"(w[N]), [p##N] "v"(N < NA ? pA : pB), [e##N] "v"(N < NA ? eA : eB),
 #define MFL_CORR_X(I, N) [x##I##_##N] "v"(N < NA ? v.A[I] : v.B[I]),
 #define MFL_CORR_XS(I) MFL_KS_LIST(MFL_CORR_X, I)
-// s[96:97] hold the jump target: named registers because the two halves are added separately
+// s[96:97] hold the jump target: named registers because the two halves are added separately.
+// The jump lands at (address after s_getpc) + 12 + step * MFL_CORR_STRIDE: the assembler checks that
+// the three instructions before the first body take 12 bytes and that the bodies together take
+// CH * MFL_CORR_STRIDE bytes (all bodies are the same instruction sequence), so that another encoding
+// of one of these instructions fails the build instead of moving the landing point.
+#define MFL_STR_(x) #x
+#define MFL_STR(x) MFL_STR_(x)
+#define MFL_CORR_SIZE_CHECKS                                                                              \
+    ".if (8b - 7b) != 12\n\t.error \"slot correction: jump preamble is not 12 bytes\"\n\t.endif\n\t"           \
+    ".if (9b - 8b) != " MFL_STR(MFL_DIAG_CH) " * " MFL_CORR_STRIDE "\n\t"                                    \
+    ".error \"slot correction: step bodies do not have the size the computed jump assumes\"\n\t.endif\n\t"
 #define MFL_CORR_SLOT()                                                                                   \
     asm volatile(MFL_CORR_SELS                                                                            \
                  "s_mul_i32 %[tmp], %[st], " MFL_CORR_STRIDE "\n\ts_add_u32 %[tmp], %[tmp], 12\n\t"      \
-                 "s_getpc_b64 s[96:97]\n\ts_add_u32 s96, s96, %[tmp]\n\ts_addc_u32 s97, s97, 0\n\t"     \
-                 "s_setpc_b64 s[96:97]\n\t"                                                               \
-                 MFL_CORR_LIST(MFL_CORR_BODY) "9:"                                                        \
+                 "s_getpc_b64 s[96:97]\n\t7:\n\ts_add_u32 s96, s96, %[tmp]\n\ts_addc_u32 s97, s97, 0\n\t" \
+                 "s_setpc_b64 s[96:97]\n\t8:\n\t"                                                        \
+                 MFL_CORR_LIST(MFL_CORR_BODY) "9:\n\t" MFL_CORR_SIZE_CHECKS                              \
                  : MFL_CORR_LIST(MFL_CORR_ACCS) MFL_KS_LIST(MFL_CORR_TMP, 0)[d] "=&v"(d), [tmp] "=&s"(tmp) \
                  : MFL_KS_LIST(MFL_CORR_IN, 0) MFL_CORR_LIST(MFL_CORR_XS)[st] "s"(step)                   \
                  : "vcc", "scc", "s96", "s97", "s98", "s99")

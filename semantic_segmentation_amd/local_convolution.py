@@ -15,6 +15,7 @@ from itertools import repeat
 from typing import Callable, Tuple, Union
 
 import torch
+from torch.autograd.function import once_differentiable
 from torch import nn
 from torch.nn.parameter import Parameter
 
@@ -78,8 +79,14 @@ class _LocalConvFunction(torch.autograd.Function):
         return ops.local_forward(x, pos_w, col_w, k, image=appearance)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         x, appearance, pos_w, col_w = ctx.saved_tensors
+        if not ctx.from_cd and ctx.needs_input_grad[1]:
+            # the reference's autograd would reach the image through its colour distance
+            # (AdvancedModel.py:520-551); the fused kernels do not compute that gradient
+            raise RuntimeError("Conv2dLocal: no gradient for the image behind a ColorDistanceHandle; "
+                               "detach the image or pass a materialised colour-distance tensor")
         want_dcd = ctx.from_cd and ctx.needs_input_grad[1]
         kw = {"cd": appearance} if ctx.from_cd else {"image": appearance}
         dx, dparams, dcd = ops.local_backward(x, pos_w, col_w, ctx.k, dy, want_dcd=want_dcd, **kw)

@@ -24,6 +24,20 @@ from . import ops
 from .local_convolution import Conv2dLocal, ColorDistanceHandle, _require_square
 
 
+class LinearActivation(nn.Module):
+    """Per-pixel, per-label affine w * x + b with the parameter names and shapes of the reference's
+    LinearActivation (AdvancedModel.py:38-56), so that its state-dict keys load here; initialised to the
+    identity (the reference leaves the tensors uninitialised, AdvancedModel.py:41-43)."""
+
+    def __init__(self, num_channels: int, height: int, width: int):
+        super().__init__()
+        self.weight = Parameter(torch.ones(1, num_channels, height, width))
+        self.bias = Parameter(torch.zeros(1, num_channels, height, width))
+
+    def forward(self, input_tensor: torch.Tensor) -> torch.Tensor:
+        return self.weight * input_tensor + self.bias
+
+
 class MeanFieldLocal(nn.Module):
     def __init__(self, in_height: int, in_width: int, channels: int, kernel_size: Union[int, Tuple[int, int]],
                  iters: int = 1, compat: bool = False, affine: bool = False):
@@ -33,11 +47,8 @@ class MeanFieldLocal(nn.Module):
         self.iters = iters
         # parameter names follow the reference model's state dict (AdvancedModel.py:136-138)
         self.local_convolution_layer = Conv2dLocal(in_height, in_width, channels, kernel_size)
-        if affine:
-            self.affine_weight = Parameter(torch.ones(1, channels, in_height, in_width))
-            self.affine_bias = Parameter(torch.zeros(1, channels, in_height, in_width))
-        else:
-            self.affine_weight = self.affine_bias = None
+        # (keys local_activation_function.weight / .bias, AdvancedModel.py:138)
+        self.local_activation_function = LinearActivation(channels, in_height, in_width) if affine else None
         self.compat = Parameter(1.0 - torch.eye(channels)) if compat else None
 
     def forward(self, unary: torch.Tensor, image: torch.Tensor) -> torch.Tensor:
@@ -47,16 +58,18 @@ class MeanFieldLocal(nn.Module):
         needs_grad = torch.is_grad_enabled() and (
             unary.requires_grad or any(p.requires_grad for p in self.parameters()))
         if not needs_grad:
+            act = self.local_activation_function
             return ops.meanfield_forward(unary, image, local.position_weight, local.color_weight, k, self.iters,
-                                         self.affine_weight, self.affine_bias, self.compat)
+                                         None if act is None else act.weight, None if act is None else act.bias,
+                                         self.compat)
         handle = ColorDistanceHandle(image, local.kernel_size)
         ls_unary = functional.log_softmax(unary, dim=1)
         q = unary
         logq = None
         for _ in range(self.iters):
             msg = local(q, handle)
-            if self.affine_weight is not None:
-                msg = self.affine_weight * msg + self.affine_bias
+            if self.local_activation_function is not None:
+                msg = self.local_activation_function(msg)
             if self.compat is not None:
                 msg = torch.einsum("ij,bjhw->bihw", self.compat, msg)
             logq = functional.log_softmax(ls_unary - msg, dim=1)

@@ -146,3 +146,10 @@ extern "C" int emu_diag_local_forward(const float *x, const float *img, float pw
     }
     return 0;
 }
+
+// Status of the geometry alone (0, -1 unsupported, -3 too large for 32-bit offsets): no table, no data.
+extern "C" int emu_diag_geom_status(int B, int C, int H, int W, int k)
+{
+    DiagGeom g;
+    return make_diag_geom(g, B, C, H, W, k, 96 * 1024);
+}

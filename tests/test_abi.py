@@ -54,6 +54,14 @@ def test_workspace_bytes(mfl):
     assert ws(mfl.OP_LOCAL_FORWARD, 1, 150, 4096, 4096, 50, 1) == 0
 
 
+def test_one_channel_image_past_the_32_bit_pixel_offsets(mfl, emu_diag):
+    """The diagonal kernels reach the 16-byte pixels of the padded image through 32-bit byte offsets:
+    a one-channel 11600 x 11600 problem passes the bound on the fp32 planes (< 2^31 bytes) and must
+    still be refused by the geometry (served by the generic kernels instead)."""
+    assert emu_diag.emu_diag_geom_status(1, 1, 11500, 11500, 7) == 0        # 132 M pixels x 16 B < 2^31
+    assert emu_diag.emu_diag_geom_status(1, 1, 11600, 11600, 7) == -3       # 134.7 M pixels x 16 B >= 2^31
+
+
 def test_invalid_arguments_are_rejected_on_the_host(mfl):
     L = mfl.lib
     one = ctypes.c_void_p(16)        # never dereferenced: the argument checks fail first
@@ -70,6 +78,10 @@ def test_invalid_arguments_are_rejected_on_the_host(mfl):
     assert L.mfl_meanfield_forward(one, one, one, one, None, None, None, one, 1, 2, 4, 4, 3, 0, one, 1 << 20, None) == -1
     assert L.mfl_combine_forward(one, one, 0, one, None, 1, 2, 4, 4, None) == -1
     assert L.mfl_argmax_labels(one, one, 1, 300, 4, 4, None) == -1
+    # more labels than the label transform's LDS tile holds (64 pixels x C floats in 160 KB): rejected before any launch
+    assert L.mfl_meanfield_forward(one, one, one, one, None, None, one, one, 1, 700, 8, 8, 3, 1, one, 1 << 30, None) == -1
+    # scratch-less entry point: a problem past the built-in buffer is refused on the host
+    assert L.mfl_meanfield_forward_noalloc(one, one, one, one, None, None, None, one, 8, 21, 512, 512, 7, 1, None) == -4
     with pytest.raises(ValueError):
         mfl.check(-1, "x")
     with pytest.raises(mfl.MflError):

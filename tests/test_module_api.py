@@ -54,6 +54,6 @@ def test_meanfield_module_parameters():
     m = S.MeanFieldLocal(8, 8, 5, 3, iters=4, compat=True, affine=True)
     names = [n for n, _ in m.named_parameters()]
     assert "local_convolution_layer.position_weight" in names and "local_convolution_layer.color_weight" in names
-    assert m.compat.shape == (5, 5) and m.affine_weight.shape == (1, 5, 8, 8)
+    assert m.compat.shape == (5, 5) and m.local_activation_function.weight.shape == (1, 5, 8, 8)
     with pytest.raises(ValueError):
         S.MeanFieldLocal(8, 8, 5, 3, iters=0)
