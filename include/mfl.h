@@ -56,6 +56,7 @@ extern "C" {
 #define MFL_OP_LOCAL_FORWARD 1
 #define MFL_OP_LOCAL_BACKWARD 2
 #define MFL_OP_MEANFIELD_FORWARD 3
+#define MFL_OP_MEANFIELD_BACKWARD 4
 
 typedef void *mfl_stream_t;
 
@@ -68,7 +69,7 @@ const char *mfl_error_string(int code);
 /*
  * Bytes of device workspace the given operation needs for this problem size
  * (0 if the operation needs none or the arguments are invalid).  `iters` is
- * only read for MFL_OP_MEANFIELD_FORWARD.
+ * only read for MFL_OP_MEANFIELD_BACKWARD.
  */
 size_t mfl_workspace_bytes(int op, int B, int C, int H, int W, int k, int iters);
 
@@ -137,6 +138,25 @@ int mfl_meanfield_forward(const float *unary, const float *img, const float *pos
                           const float *affine_w, const float *affine_b, const float *compat, float *logq, int B,
                           int C, int H, int W, int k, int iters, void *workspace, size_t workspace_bytes,
                           mfl_stream_t stream);
+
+/*
+ * Gradients of mfl_meanfield_forward for an incoming grad_logq = dL/dlogq: what
+ * autograd derives when loss.backward() (AdvancedModel.py:299) runs through the
+ * iterated composition AdvancedModel.py:222-244 (see mfl_meanfield_forward).
+ * The forward loop is recomputed inside the call with every iterate kept in the
+ * workspace (mfl_workspace_bytes(MFL_OP_MEANFIELD_BACKWARD, ...) grows with iters).
+ *   grad_logq, d_unary: [B][C][H][W]
+ *   dparams:    2 floats, overwritten with {d position_weight, d color_weight}
+ *   d_affine_w, d_affine_b: [C][H][W], overwritten; non-NULL exactly when affine_w is
+ *   d_compat:   [C][C], overwritten; non-NULL exactly when compat is
+ * C <= 32.  All sums over images and pixels outside the local operator's own
+ * backward have a fixed order.
+ */
+int mfl_meanfield_backward(const float *unary, const float *img, const float *pos_w, const float *col_w,
+                           const float *affine_w, const float *affine_b, const float *compat, const float *grad_logq,
+                           float *d_unary, float *dparams, float *d_affine_w, float *d_affine_b, float *d_compat,
+                           int B, int C, int H, int W, int k, int iters, void *workspace, size_t workspace_bytes,
+                           mfl_stream_t stream);
 
 /*
  * mfl_meanfield_forward without a workspace argument, for callers that cannot

@@ -103,3 +103,66 @@ def meanfield_forward(unary, img, pw, cw, k, iters, affine_w=None, affine_b=None
     lib().mflo_meanfield_forward(_p(unary), _p(img), ctypes.c_float(pw), ctypes.c_float(cw), _p(aw), _p(ab), _p(cm),
                                  _p(logq), B, C, H, W, k, iters)
     return logq
+
+
+def _log_softmax(z):
+    m = z.max(axis=1, keepdims=True)
+    return z - m - np.log(np.exp(z - m).sum(axis=1, keepdims=True))
+
+
+def meanfield_backward(unary, img, pw, cw, k, iters, grad_logq, affine_w=None, affine_b=None, compat=None):
+    """Gradients of sum(logq_K * grad_logq) through the K-iteration loop, i.e. what autograd derives
+    from the composition AdvancedModel.py:222-244 iterated (loss.backward(), AdvancedModel.py:299).
+
+    Restated by hand, iteration t = K-1 .. 0, with z_t = log_softmax(U) - P_t:
+        logQ_{t+1} = z_t - lse(z_t)        =>  dz = g - Q_{t+1} * sum_c g
+        P_t = compat . A_t                  =>  dA = compat^T . dP (dP = -dz),  dcompat += sum dP (x) A_t
+        A_t = aw * M_t + ab                 =>  dM = aw * dA,  daw += sum_b dA * M_t,  dab += sum_b dA
+        M_t = Conv2dLocal(Q_t)              =>  (dQ_t, dpw, dcw) by the local backward (LocalConvolution.py:59-90)
+        Q_t = exp(logQ_t)  (t > 0)          =>  g <- dQ_t * Q_t;      Q_0 = U: dU += dQ_0
+    and dU += d log_softmax(U) for the summed dz.  Elementwise steps in float64, the two local operators by
+    the C oracle (fp32 storage, double accumulation).  Returns a dict of float64 arrays / floats."""
+    U = np.asarray(unary, np.float64)
+    B, C, H, W = U.shape
+    aw = None if affine_w is None else np.asarray(affine_w, np.float64).reshape(1, C, H, W)
+    ab = None if affine_b is None else np.asarray(affine_b, np.float64).reshape(1, C, H, W)
+    cm = None if compat is None else np.asarray(compat, np.float64).reshape(C, C)
+    ls_u = _log_softmax(U)
+    # forward, keeping every Q_t and M_t
+    qs, ms = [U], []
+    for _ in range(iters):
+        m = local_forward(qs[-1], pw, cw, k, img=img).astype(np.float64)
+        ms.append(m)
+        a = m if aw is None else aw * m + ab
+        p = a if cm is None else np.einsum("ij,bjhw->bihw", cm, a)
+        qs.append(np.exp(_log_softmax(ls_u - p)))
+    g = np.asarray(grad_logq, np.float64)
+    d_ls = np.zeros_like(U)
+    out = {"dpw": 0.0, "dcw": 0.0, "dcompat": np.zeros((C, C)), "daw": np.zeros((C, H, W)), "dab": np.zeros((C, H, W))}
+    for t in range(iters - 1, -1, -1):
+        dz = g - qs[t + 1] * g.sum(axis=1, keepdims=True)
+        d_ls += dz
+        dp = -dz
+        a = ms[t] if aw is None else aw * ms[t] + ab
+        if cm is None:
+            da = dp
+        else:
+            out["dcompat"] += np.einsum("bihw,bjhw->ij", dp, a)
+            da = np.einsum("ij,bihw->bjhw", cm, dp)
+        if aw is None:
+            dm = da
+        else:
+            out["daw"] += (da * ms[t]).sum(axis=0)
+            out["dab"] += da.sum(axis=0)
+            dm = aw * da
+        dq, dpw, dcw = local_backward(qs[t], pw, cw, k, dm, img=img)
+        out["dpw"] += dpw
+        out["dcw"] += dcw
+        dq = dq.astype(np.float64)
+        if t > 0:
+            g = dq * qs[t]
+        else:
+            d_u0 = dq
+    out["dU"] = d_u0 + d_ls - np.exp(ls_u) * d_ls.sum(axis=1, keepdims=True)
+    out["logq"] = np.log(qs[-1])
+    return out

@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("MFL_LIBRARY") or os.path.join(_HERE, "libmfl.so")
 OP_LOCAL_FORWARD = 1
 OP_LOCAL_BACKWARD = 2
 OP_MEANFIELD_FORWARD = 3
+OP_MEANFIELD_BACKWARD = 4
 
 _c_int, _c_size, _c_void = ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p
 
@@ -31,6 +32,7 @@ SIGNATURES = {
     "mfl_local_backward": (_c_int, [_c_void] * 9 + [_c_int] * 5 + [_c_void, _c_size, _c_void]),
     "mfl_combine_forward": (_c_int, [_c_void, _c_void, _c_int, _c_void, _c_void] + [_c_int] * 4 + [_c_void]),
     "mfl_meanfield_forward": (_c_int, [_c_void] * 8 + [_c_int] * 6 + [_c_void, _c_size, _c_void]),
+    "mfl_meanfield_backward": (_c_int, [_c_void] * 13 + [_c_int] * 6 + [_c_void, _c_size, _c_void]),
     "mfl_meanfield_forward_noalloc": (_c_int, [_c_void] * 8 + [_c_int] * 6 + [_c_void]),
     "mfl_argmax_labels": (_c_int, [_c_void, _c_void] + [_c_int] * 4 + [_c_void]),
 }

@@ -672,6 +672,10 @@ int scratch_pointer(void **out)
 
 }  // namespace
 
+namespace mfl {
+size_t loop_backward_workspace_bytes(int B, int C, int H, int W, int k, int iters);   // mfl_loop_backward.hip
+}
+
 // ------------------------------------------------------------------ C ABI
 
 extern "C" {
@@ -696,7 +700,7 @@ const char *mfl_error_string(int code)
 
 size_t mfl_workspace_bytes(int op, int B, int C, int H, int W, int k, int iters)
 {
-    (void)iters;
+    if (op == MFL_OP_MEANFIELD_BACKWARD) return mfl::loop_backward_workspace_bytes(B, C, H, W, k, iters);
     if (op != MFL_OP_LOCAL_FORWARD && op != MFL_OP_LOCAL_BACKWARD && op != MFL_OP_MEANFIELD_FORWARD) return 0;
     RingGeom rg;
     if (ring_eligible(op, B, C, H, W, k, rg) && !(op == MFL_OP_MEANFIELD_FORWARD && C > 32)) {
@@ -891,15 +895,22 @@ int mfl_combine_forward(const float *unary, const float *smooth, int mixtures, f
     return (int)hipGetLastError();
 }
 
-int mfl_meanfield_forward(const float *unary, const float *img, const float *pos_w, const float *col_w,
-                          const float *affine_w, const float *affine_b, const float *compat, float *logq, int B,
-                          int C, int H, int W, int k, int iters, void *workspace, size_t workspace_bytes,
-                          mfl_stream_t stream)
+// The mean-field loop.  logq_all (optional): receives logQ_{t+1} of every iteration t at
+// logq_all + t * B*C*H*W (the loop backward re-reads them); logq (optional then) the last one.
+static int meanfield_forward_impl(const float *unary, const float *img, const float *pos_w, const float *col_w,
+                                  const float *affine_w, const float *affine_b, const float *compat, float *logq,
+                                  float *logq_all, int B, int C, int H, int W, int k, int iters, void *workspace,
+                                  size_t workspace_bytes, mfl_stream_t stream)
 {
     int rc = check_common(unary, img, B, C, H, W, k);
     if (rc) return rc;
-    if (!logq || !pos_w || !col_w || iters <= 0 || (affine_w == nullptr) != (affine_b == nullptr))
+    if ((!logq && !logq_all) || !pos_w || !col_w || iters <= 0 || (affine_w == nullptr) != (affine_b == nullptr))
         return MFL_ERR_INVALID_ARGUMENT;
+    const size_t n_all = (size_t)B * C * H * W;
+    auto out_of = [&](int it) -> float * {
+        if (logq_all) return logq_all + (size_t)it * n_all;
+        return it == iters - 1 ? logq : nullptr;
+    };
     RingGeom rg;
     if (C <= 32 && ring_eligible(MFL_OP_MEANFIELD_FORWARD, B, C, H, W, k, rg)) {
         const DiagGeom &g = rg.d;
@@ -934,7 +945,7 @@ int mfl_meanfield_forward(const float *unary, const float *img, const float *pos
         for (int it = 0; it < iters; ++it) {
             ra.xp = qa;
             ra.qp_out = qb;
-            ra.logq = (it == iters - 1) ? logq : nullptr;
+            ra.logq = out_of(it);
             rc = dispatch_ring(ra, 0, st);
             if (rc) return rc;
             float *t = qa; qa = qb; qb = t;
@@ -973,7 +984,7 @@ int mfl_meanfield_forward(const float *unary, const float *img, const float *pos
         for (int it = 0; it < iters; ++it) {
             da.xp = qa;
             da.qp_out = qb;
-            da.logq = (it == iters - 1) ? logq : nullptr;
+            da.logq = out_of(it);
             rc = dispatch_diag(da, 0, st);
             if (rc) return rc;
             float *t = qa; qa = qb; qb = t;
@@ -1001,7 +1012,7 @@ int mfl_meanfield_forward(const float *unary, const float *img, const float *pos
     MFL_CHECK_HIP(hipMemsetAsync(qb, 0, padded_floats(g) * 4, st)); // borders of the other buffer
     const size_t npix = (size_t)B * g.L;
     for (int it = 0; it < iters; ++it) {
-        float *lq = (it == iters - 1) ? logq : nullptr;
+        float *lq = out_of(it);
         if (fused) {
             const GatherArgs ga{g, false, tab_lds, qa, ip4, nullptr, tab, pos_w, col_w};
             const StepArgs sa{unary, affine_w, affine_b, compat, lq, qb};
@@ -1031,6 +1042,16 @@ int mfl_meanfield_forward(const float *unary, const float *img, const float *pos
     return MFL_OK;
 }
 
+int mfl_meanfield_forward(const float *unary, const float *img, const float *pos_w, const float *col_w,
+                          const float *affine_w, const float *affine_b, const float *compat, float *logq, int B,
+                          int C, int H, int W, int k, int iters, void *workspace, size_t workspace_bytes,
+                          mfl_stream_t stream)
+{
+    if (!logq) return MFL_ERR_INVALID_ARGUMENT;
+    return meanfield_forward_impl(unary, img, pos_w, col_w, affine_w, affine_b, compat, logq, nullptr, B, C, H, W, k, iters,
+                                  workspace, workspace_bytes, stream);
+}
+
 int mfl_meanfield_forward_noalloc(const float *unary, const float *img, const float *pos_w, const float *col_w,
                                   const float *affine_w, const float *affine_b, const float *compat, float *logq,
                                   int B, int C, int H, int W, int k, int iters, mfl_stream_t stream)
@@ -1056,3 +1077,17 @@ int mfl_argmax_labels(const float *logq, unsigned char *labels, int B, int C, in
 }
 
 }  // extern "C"
+
+namespace mfl {
+
+// The forward loop with logQ_{t+1} of every iteration kept (for the loop backward, mfl_loop_backward.hip).
+int meanfield_forward_keep(const float *unary, const float *img, const float *pos_w, const float *col_w, const float *affine_w,
+                           const float *affine_b, const float *compat, float *logq_all, int B, int C, int H, int W, int k,
+                           int iters, void *workspace, size_t workspace_bytes, mfl_stream_t stream)
+{
+    if (!logq_all) return MFL_ERR_INVALID_ARGUMENT;
+    return meanfield_forward_impl(unary, img, pos_w, col_w, affine_w, affine_b, compat, nullptr, logq_all, B, C, H, W, k, iters,
+                                  workspace, workspace_bytes, stream);
+}
+
+}  // namespace mfl

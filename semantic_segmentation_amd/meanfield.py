@@ -7,9 +7,10 @@ Per iteration (every step is one of the reference's modules, only the loop is ne
     logQ = LogSoftmax(log_softmax(U) - P)                     AdvancedModel.py:242-244
     Q_{t+1} = exp(logQ),  Q_0 = U                             AdvancedModel.py:222
 
-Inference (no gradient required) runs the fused C-ABI loop.  When a gradient is required the
-same arithmetic is composed per iteration from the HIP local operator (with its HIP backward)
-and stock differentiable torch ops for the normalisation.
+The forward is always the fused C-ABI loop.  When a gradient is required, the backward is the library's
+loop backward (recompute with checkpoints, mfl_meanfield_backward) for up to 32 labels; above that the same
+arithmetic is composed per iteration from the HIP local operator (with its HIP backward) and stock
+differentiable torch ops for the normalisation.
 """
 from __future__ import annotations
 
@@ -17,6 +18,7 @@ from typing import Optional, Tuple, Union
 
 import torch
 from torch import nn
+from torch.autograd.function import once_differentiable
 from torch.nn import functional
 from torch.nn.parameter import Parameter
 
@@ -36,6 +38,30 @@ class LinearActivation(nn.Module):
 
     def forward(self, input_tensor: torch.Tensor) -> torch.Tensor:
         return self.weight * input_tensor + self.bias
+
+
+class _MeanFieldFunction(torch.autograd.Function):
+    """logq = K fused mean-field updates; backward by the library's loop backward."""
+
+    @staticmethod
+    def forward(ctx, unary, image, pos_w, col_w, affine_w, affine_b, compat, k, iters):
+        ctx.k, ctx.iters = k, iters
+        ctx.save_for_backward(unary, image, pos_w, col_w, affine_w, affine_b, compat)
+        return ops.meanfield_forward(unary, image, pos_w, col_w, k, iters, affine_w, affine_b, compat)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_logq):
+        unary, image, pos_w, col_w, affine_w, affine_b, compat = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:
+            raise RuntimeError("MeanFieldLocal: no gradient for the image; detach it")
+        d_unary, dparams, d_aw, d_ab, d_compat = ops.meanfield_backward(
+            unary, image, pos_w, col_w, ctx.k, ctx.iters, grad_logq, affine_w, affine_b, compat)
+        need = ctx.needs_input_grad
+        return (d_unary if need[0] else None, None, dparams[0:1] if need[2] else None, dparams[1:2] if need[3] else None,
+                d_aw.reshape(affine_w.shape) if (d_aw is not None and need[4]) else None,
+                d_ab.reshape(affine_b.shape) if (d_ab is not None and need[5]) else None,
+                d_compat if (d_compat is not None and need[6]) else None, None, None)
 
 
 class MeanFieldLocal(nn.Module):
@@ -62,6 +88,11 @@ class MeanFieldLocal(nn.Module):
             return ops.meanfield_forward(unary, image, local.position_weight, local.color_weight, k, self.iters,
                                          None if act is None else act.weight, None if act is None else act.bias,
                                          self.compat)
+        if unary.shape[1] <= ops.MEANFIELD_BACKWARD_MAX_LABELS:
+            act = self.local_activation_function
+            return _MeanFieldFunction.apply(unary, image, local.position_weight, local.color_weight,
+                                            None if act is None else act.weight, None if act is None else act.bias,
+                                            self.compat, k, self.iters)
         handle = ColorDistanceHandle(image, local.kernel_size)
         ls_unary = functional.log_softmax(unary, dim=1)
         q = unary

@@ -211,17 +211,73 @@ def gen_meanfield(LC, AM):
              k=np.int64(k), pw=np.float32(pw), cw=np.float32(cw), **extra)
 
 
+def gen_meanfield_grad(LC, AM):
+    """Autograd gradients through the same K-iteration composition (what loss.backward(),
+    AdvancedModel.py:299, derives), for K in {1, 2, 5}, on the inputs of the three meanfield_* cases:
+    loss = sum(logq_K * G) with a stored cotangent G."""
+    import glob
+    for ci, path in enumerate(sorted(glob.glob(os.path.join(HERE, "meanfield_l*.npz")))):
+        d = dict(np.load(path, allow_pickle=False))
+        k, pw, cw = int(d["k"]), float(d["pw"]), float(d["cw"])
+        B, L, H, W = d["unary"].shape
+        affine = "la_w" in d
+        g = torch.Generator().manual_seed(606 + ci)
+        G = torch.randn(B, L, H, W, generator=g)
+        out = {key: d[key] for key in ("unary", "img", "compat", "k", "pw", "cw")}
+        if affine:
+            out.update(la_w=d["la_w"], la_b=d["la_b"])
+        out["G"] = npy(G)
+        for dtype, tag in ((torch.float32, ""), (torch.float64, "64")):
+            for K in (1, 2, 5):
+                local = LC.Conv2dLocal(H, W, L, k)
+                conv = nn.Conv2d(L, L, kernel_size=1, bias=False)
+                la = AM.LinearActivation(L, H, W)
+                with torch.no_grad():
+                    local.position_weight.fill_(pw)
+                    local.color_weight.fill_(cw)
+                    conv.weight.copy_(torch.from_numpy(d["compat"]).reshape(L, L, 1, 1))
+                    if affine:
+                        la.weight.copy_(torch.from_numpy(d["la_w"]))
+                        la.bias.copy_(torch.from_numpy(d["la_b"]))
+                conv, la = conv.to(dtype), la.to(dtype)
+                act = la if affine else (lambda t: t)
+                cdf = AM.DPNModel._color_distance(kernel_size=(k, k), channels=3)
+                U = torch.from_numpy(d["unary"]).to(dtype).requires_grad_(True)
+                cd = cdf(torch.from_numpy(d["img"]).to(dtype))
+                q = U
+                for _ in range(K):
+                    msg = conv(act(local(q, cd)))
+                    logq = nn.LogSoftmax(dim=1)(torch.nn.functional.log_softmax(U, dim=1) - msg)
+                    q = torch.exp(logq)
+                (logq * G.to(dtype)).sum().backward()
+                sfx = f"{tag}_K{K}"
+                out[f"logq{sfx}"] = npy(logq)
+                out[f"dU{sfx}"] = npy(U.grad)
+                out[f"dpw{sfx}"] = npy(local.position_weight.grad)
+                out[f"dcw{sfx}"] = npy(local.color_weight.grad)
+                out[f"dcompat{sfx}"] = npy(conv.weight.grad.reshape(L, L))
+                if affine:
+                    out[f"dla_w{sfx}"] = npy(la.weight.grad)
+                    out[f"dla_b{sfx}"] = npy(la.bias.grad)
+        save("mfgrad_" + os.path.basename(path)[len("meanfield_"):-len(".npz")], **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None, help="run one generator (e.g. meanfield_grad)")
     ap.add_argument("--reference", default="/root/reference")
     args = ap.parse_args()
     torch.set_num_threads(4)
     LC, AM = import_reference(args.reference)
+    if args.only == "meanfield_grad":
+        gen_meanfield_grad(LC, AM)
+        return
     gen_color_distance(AM)
     gen_local(LC)
     gen_tail(AM)
     gen_dpn(AM)
     gen_meanfield(LC, AM)
+    gen_meanfield_grad(LC, AM)
 
 
 if __name__ == "__main__":

@@ -194,6 +194,56 @@ def test_meanfield_vs_oracle(shape, mode, S, oracle):
         assert decided.mean() > 0.5
 
 
+def _loop_backward(S, d, K, affine):
+    opt = lambda a: None if a is None else dev(a)
+    return S.ops.meanfield_backward(dev(d["unary"]), dev(d["img"]), scalar(d["pw"]), scalar(d["cw"]), int(d["k"]), K,
+                                    dev(d["G"]), opt(d.get("la_w") if affine else None),
+                                    opt(d.get("la_b") if affine else None), opt(d["compat"]))
+
+
+@pytest.mark.parametrize("path", golden_files("mfgrad"))
+def test_meanfield_backward_golden(path, S):
+    """mfl_meanfield_backward against the reference's autograd gradients through the iterated composition
+    (tests/golden/make_golden.py: gen_meanfield_grad), K = 1, 2, 5, at 1e-4."""
+    d = load(path)
+    affine = "la_w" in d
+    for K in (1, 2, 5):
+        du, dpar, daw, dab, dcompat = _loop_backward(S, d, K, affine)
+        assert_close(host(du), d[f"dU64_K{K}"], RTOL, f"dU K={K}")
+        assert_close(host(dcompat), d[f"dcompat64_K{K}"], RTOL, f"dcompat K={K}")
+        for got, key in ((dpar[0], "dpw"), (dpar[1], "dcw")):
+            want = float(d[f"{key}64_K{K}"][0])
+            assert abs(float(got) - want) <= 2e-4 * abs(want) + 1e-6, (key, K, float(got), want)
+        if affine:
+            assert_close(host(daw).reshape(d["la_w"].shape), d[f"dla_w64_K{K}"], RTOL, f"d affine w K={K}")
+            assert_close(host(dab).reshape(d["la_b"].shape), d[f"dla_b64_K{K}"], RTOL, f"d affine b K={K}")
+
+
+@pytest.mark.parametrize("shape,iters", [((2, 21, 64, 96, 7), 3), ((1, 19, 96, 128, 11), 2), ((2, 8, 40, 44, 5), 4)])
+def test_meanfield_backward_vs_oracle(shape, iters, S, oracle):
+    """Loop backward on shapes that take the diagonal and the stream kernels, against the oracle's restatement."""
+    B, C, H, W, k = shape
+    unary, img, _ = make_inputs(shape, 11)
+    rng = np.random.default_rng(12)
+    compat = ((1 - np.eye(C)) + 0.01 * rng.standard_normal((C, C))).astype(np.float32)
+    aw = (1 + 0.2 * rng.standard_normal((1, C, H, W))).astype(np.float32)
+    ab = (0.1 * rng.standard_normal((1, C, H, W))).astype(np.float32)
+    G = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    du, dpar, daw, dab, dcompat = S.ops.meanfield_backward(dev(unary), dev(img), scalar(-0.004), scalar(-0.003), k, iters,
+                                                           dev(G), dev(aw), dev(ab), dev(compat))
+    ref = oracle.meanfield_backward(unary, img, -0.004, -0.003, k, iters, G, aw, ab, compat)
+    assert_close(host(du), ref["dU"], RTOL, "dU")
+    assert_close(host(dcompat), ref["dcompat"], RTOL, "dcompat")
+    assert_close(host(daw).reshape(C, H, W), ref["daw"], RTOL, "d affine w")
+    assert_close(host(dab).reshape(C, H, W), ref["dab"], RTOL, "d affine b")
+    assert abs(float(dpar[0]) - ref["dpw"]) <= 2e-4 * abs(ref["dpw"]) + 1e-6
+    assert abs(float(dpar[1]) - ref["dcw"]) <= 2e-4 * abs(ref["dcw"]) + 1e-6
+    # the deterministic parts: everything but the local operator's scatter
+    again = S.ops.meanfield_backward(dev(unary), dev(img), scalar(-0.004), scalar(-0.003), k, iters, dev(G), dev(aw), dev(ab),
+                                     dev(compat))
+    assert_close(host(again[0]), host(du), 1e-6, "dU, second run")
+
+
 def test_150_labels_meanfield_vs_oracle(S, oracle):
     """Large-label configuration: unfused path (gather in channel chunks, LxL transform, normalise)."""
     shape = (1, 150, 12, 14, 7)
@@ -271,20 +321,38 @@ def test_module_forward_backward_like_reference(S, oracle):
     assert_close(host(out2), host(out), 1e-5, "tensor form")
 
 
-def test_meanfield_module_grad_path_matches_fused(S):
-    """With gradients enabled the module composes the loop from the HIP local operator and torch ops;
-    it must agree with the fused inference loop."""
+def test_meanfield_module_gradients_match_composed_torch_ops(S):
+    """MeanFieldLocal under autograd (fused forward + the library's loop backward) against the same loop
+    composed per iteration from the HIP local operator and differentiable torch ops."""
     B, C, H, W, k = 2, 5, 20, 24, 3
     unary, img, _ = make_inputs((B, C, H, W, k), 7)
     mod = S.MeanFieldLocal(H, W, C, k, iters=3, compat=True, affine=True).cuda()
     with torch.no_grad():
         mod.local_convolution_layer.position_weight.fill_(-0.004)
         mod.local_convolution_layer.color_weight.fill_(-0.003)
+        mod.local_activation_function.weight.add_(0.1 * torch.randn_like(mod.local_activation_function.weight))
         fused = mod(dev(unary), dev(img))
+    target = torch.randint(0, C, (B, H, W), device="cuda")
     U = dev(unary).requires_grad_(True)
-    composed = mod(U, dev(img))
-    assert_close(host(composed), host(fused), RTOL, "composed vs fused")
-    loss = torch.nn.functional.nll_loss(composed, torch.randint(0, C, (B, H, W), device="cuda"))
-    loss.backward()
-    for p in list(mod.parameters()) + [U]:
-        assert p.grad is not None and torch.isfinite(p.grad).all()
+    out = mod(U, dev(img))
+    assert_close(host(out), host(fused), 1e-6, "forward under autograd vs inference")
+    torch.nn.functional.nll_loss(out, target).backward()
+    got = {n: p.grad.clone() for n, p in mod.named_parameters()}
+    got["U"] = U.grad.clone()
+    # the composed loop
+    for p in mod.parameters():
+        p.grad = None
+    U2 = dev(unary).requires_grad_(True)
+    local = mod.local_convolution_layer
+    handle = S.ColorDistanceHandle(dev(img), local.kernel_size)
+    q, ls = U2, torch.nn.functional.log_softmax(U2, dim=1)
+    for _ in range(3):
+        msg = torch.einsum("ij,bjhw->bihw", mod.compat, mod.local_activation_function(local(q, handle)))
+        logq = torch.nn.functional.log_softmax(ls - msg, dim=1)
+        q = torch.exp(logq)
+    torch.nn.functional.nll_loss(logq, target).backward()
+    want = {n: p.grad for n, p in mod.named_parameters()}
+    want["U"] = U2.grad
+    for n in want:
+        assert got[n] is not None and torch.isfinite(got[n]).all(), n
+        assert_close(host(got[n]), host(want[n]), 2e-4, n)

@@ -98,3 +98,19 @@ def test_image_mode_equals_tensor_mode(oracle):
     assert np.array_equal(a[0], b[0])
     # the OpenMP reduction order of the two scalar sums is not fixed: equal to double rounding
     assert np.allclose(a[1:], b[1:], rtol=1e-12)
+
+
+@pytest.mark.parametrize("path", golden_files("mfgrad"))
+def test_oracle_loop_backward_matches_reference_autograd(path, oracle):
+    """The hand-derived backward of the K-iteration loop (oracle.meanfield_backward) against the gradients
+    the reference's modules give under autograd (fp64 run of the imported composition), K = 1, 2, 5."""
+    d = load(path)
+    for K in (1, 2, 5):
+        r = oracle.meanfield_backward(d["unary"], d["img"], float(d["pw"]), float(d["cw"]), int(d["k"]), K, d["G"],
+                                      d.get("la_w"), d.get("la_b"), d["compat"])
+        assert rel_err(r["logq"], d[f"logq64_K{K}"]) < 1e-5
+        assert rel_err(r["dU"], d[f"dU64_K{K}"]) < 1e-5
+        assert rel_err(r["dcompat"], d[f"dcompat64_K{K}"]) < 1e-5
+        assert rel_err(r["dpw"], d[f"dpw64_K{K}"]) < 1e-5 and rel_err(r["dcw"], d[f"dcw64_K{K}"]) < 1e-5
+        if "la_w" in d:
+            assert rel_err(r["daw"], d[f"dla_w64_K{K}"][0]) < 1e-5 and rel_err(r["dab"], d[f"dla_b64_K{K}"][0]) < 1e-5
