@@ -102,8 +102,11 @@ int mfl_local_forward(const float *x, const float *img, const float *cd, const f
  *   dparams: 2 floats, overwritten with {d position_weight, d color_weight}
  *   dcd:     optional [B][H*W][k*k] gradient w.r.t. the colour-distance tensor
  *            (NULL to skip; only allowed with `cd`)
- * The scatter half of dx uses float atomics: its summation order, and therefore
- * its last bits, can differ between runs.
+ * With `img` on shapes the diagonal kernels serve (images at least 64 pixels
+ * wide, window 3..11) the scatter half of dx is summed in 64-bit fixed point
+ * (integer atomics): dx is reproducible bit for bit.  The other paths (a `cd`
+ * tensor, small or very wide windows) use float atomics, whose summation order
+ * and therefore last bits can differ between runs.
  */
 int mfl_local_backward(const float *x, const float *img, const float *cd, const float *pos_w, const float *col_w,
                        const float *dy, float *dx, float *dparams, float *dcd, int B, int C, int H, int W, int k,
@@ -182,6 +185,20 @@ int mfl_meanfield_forward_noalloc(const float *unary, const float *img, const fl
  * AdvancedModel.py:420-421).   labels: [B][H][W] uint8, C <= 256.
  */
 int mfl_argmax_labels(const float *logq, unsigned char *labels, int B, int C, int H, int W, mfl_stream_t stream);
+
+/*
+ * Per-class pixel counts behind the reference's intersection-over-union
+ * (DPNModel.calc_intersection_over_union, AdvancedModel.py:448-485):
+ *   counts[0][c] = #(pred == c and target == c)    intersection
+ *   counts[1][c] = #(pred == c)
+ *   counts[2][c] = #(target == c)
+ * so that IoU_c = counts[0][c] / (counts[1][c] + counts[2][c] - counts[0][c]).
+ * counts: [3][C] unsigned 64-bit, overwritten.  pred, target: n labels (uint8, e.g.
+ * the output of mfl_argmax_labels over any number of images); labels >= C (255 =
+ * void) belong to no class.  Integer sums: the result is exact and order-free.
+ */
+int mfl_iou_counts(const unsigned char *pred, const unsigned char *target, unsigned long long *counts, size_t n, int C,
+                   mfl_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -201,6 +201,29 @@ __global__ void argmax_kernel(const float *__restrict__ logq, unsigned char *__r
     labels[pix] = (unsigned char)arg;
 }
 
+// counts[0][c] += #(pred == c and target == c), counts[1][c] += #(pred == c), counts[2][c] += #(target == c):
+// a histogram per workgroup in LDS, then one 64-bit integer atomic per workgroup and counter (integer
+// sums: the result does not depend on the order).  Labels >= C (e.g. 255 = void) fall in no class.
+__global__ void __launch_bounds__(kThreads)
+iou_counts_kernel(const unsigned char *__restrict__ pred, const unsigned char *__restrict__ target,
+                  unsigned long long *__restrict__ counts, size_t n, int C)
+{
+    extern __shared__ unsigned int hist[];       // [3][C]
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int p = pred[i], t = target[i];
+        if (p < C) atomicAdd(&hist[C + p], 1u);
+        if (t < C) {
+            atomicAdd(&hist[2 * C + t], 1u);
+            if (p == t) atomicAdd(&hist[t], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x)
+        if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
+}
+
 // dx = dxd + interior(dxp)
 __global__ void backward_finish_kernel(const float *__restrict__ dxd, const float *__restrict__ dxp,
                                        float *__restrict__ dx, int planes, int H, int W, int Hp, int Wp, int p0)
@@ -414,22 +437,73 @@ struct DiagWorkspace {
 
 constexpr int kDiagBackwardBlocks = 2048;    // blocks (and partial sums) of the backward's finishing pass
 
+// c[0..3] = the weight pairs (1, 0), (0, 1) of the two plain window sums; c[6], c[7] = 0 (maxima, as bits)
 __global__ void diag_backward_consts_kernel(float *c)
 {
-    if (threadIdx.x == 0) { c[0] = 1.f; c[1] = 0.f; c[2] = 0.f; c[3] = 1.f; }
+    if (threadIdx.x == 0) { c[0] = 1.f; c[1] = 0.f; c[2] = 0.f; c[3] = 1.f; c[6] = 0.f; c[7] = 0.f; }
 }
 
-// dx = dy * (pos_w * P + col_w * Q) + scattered term (interior of the padded gradient planes);
+// c[6] = max |dy * x|, c[7] = max |img| (bit patterns of non-negative floats order like unsigned integers;
+// a maximum does not depend on the order it is taken in).  NaNs count as the largest value.
+__global__ void __launch_bounds__(kThreads)
+diag_backward_absmax_kernel(const float *__restrict__ dy, const float *__restrict__ x, size_t n, const float *__restrict__ img,
+                            size_t nimg, float *c)
+{
+    __shared__ unsigned sh[2][kThreads];
+    unsigned md = 0, mi = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned b = __float_as_uint(dy[i] * x[i]) & 0x7fffffffu;
+        md = b > md ? b : md;
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nimg; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned b = __float_as_uint(img[i]) & 0x7fffffffu;
+        mi = b > mi ? b : mi;
+    }
+    sh[0][threadIdx.x] = md;
+    sh[1][threadIdx.x] = mi;
+    __syncthreads();
+    for (int s = kThreads / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sh[0][threadIdx.x] = sh[0][threadIdx.x] > sh[0][threadIdx.x + s] ? sh[0][threadIdx.x] : sh[0][threadIdx.x + s];
+            sh[1][threadIdx.x] = sh[1][threadIdx.x] > sh[1][threadIdx.x + s] ? sh[1][threadIdx.x] : sh[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicMax(reinterpret_cast<unsigned *>(c) + 6, sh[0][0]);
+        atomicMax(reinterpret_cast<unsigned *>(c) + 7, sh[1][0]);
+    }
+}
+
+// c[4] = scale, c[5] = 1 / scale of the fixed-point scatter: the power of two that keeps every contribution
+// |w * D| * scale below 2^50, with |w| <= |pos_w| * max pd + |col_w| * 3 * (2 max|img|)^2.
+__global__ void diag_backward_scale_kernel(const float *__restrict__ pos_w, const float *__restrict__ col_w, int k, float *c)
+{
+    if (threadIdx.x != 0) return;
+    const float pdmax = 2.f * (float)((k / 2) * (k / 2));
+    const float wmax = fabsf(*pos_w) * pdmax + fabsf(*col_w) * 12.f * c[7] * c[7];
+    const float bound = wmax * c[6];
+    int ex = 0;
+    if (bound > 0.f && bound < INFINITY) frexpf(bound, &ex);       // bound < 2^ex
+    int e = 50 - ex;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    c[4] = ldexpf(1.f, e);
+    c[5] = ldexpf(1.f, -e);
+}
+
+// dx = dy * (pos_w * P + col_w * Q) + scattered term (interior of the padded planes of fixed-point sums, consts[5] = 1 / scale);
 // partials[2*block + {0,1}] = sum of dy * x * {P, Q} (gradients of position_weight / color_weight),
 // where P / Q are the window sums with weights pd[t] / cd[l,t] alone (LocalConvolution.py:84-90).
 __global__ void __launch_bounds__(kThreads)
 diag_backward_finish_kernel(const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ P,
-                            const float *__restrict__ Q, const float *__restrict__ dxp, const float *__restrict__ pos_w,
+                            const float *__restrict__ Q, const long long *__restrict__ dxp, const float *__restrict__ consts,
+                            const float *__restrict__ pos_w,
                             const float *__restrict__ col_w, float *__restrict__ dx, float *__restrict__ partials,
                             int planes, int H, int W, int Hp, int Wp, int p0)
 {
     __shared__ float sh[2][kThreads];
     const float pw = *pos_w, cw = *col_w;
+    const double inv_scale = (double)consts[5];
     const size_t n = (size_t)planes * H * W;
     float a = 0.f, c = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -438,7 +512,7 @@ diag_backward_finish_kernel(const float *__restrict__ dy, const float *__restric
         const int yy = (int)(rest % H);
         const size_t pc = rest / H;
         const float p = P[i], q = Q[i], g = dy[i], d = g * x[i];
-        dx[i] = fmaf(g, fmaf(pw, p, cw * q), dxp[(pc * Hp + yy + p0) * Wp + xx + p0]);
+        dx[i] = fmaf(g, fmaf(pw, p, cw * q), (float)((double)dxp[(pc * Hp + yy + p0) * Wp + xx + p0] * inv_scale));
         a = fmaf(d, p, a);
         c = fmaf(d, q, c);
     }
@@ -489,10 +563,10 @@ DiagWorkspace diag_carve(int op, const DiagGeom &g)
     w.groups = take((size_t)g.k * g.k * 4);
     w.compat = take((size_t)(g.CH * g.NCS + 1) * (g.CH * g.NCS + 1) * 4);
     if (op == MFL_OP_LOCAL_BACKWARD) {
-        w.xp2 = take(diag_padded_floats(g) * 4);          // the padded gradient planes
+        w.xp2 = take(diag_padded_floats(g) * 8);          // the padded gradient planes: 64-bit fixed-point sums
         w.psum = take((size_t)g.B * g.C * g.L * 4);
         w.qsum = take((size_t)g.B * g.C * g.L * 4);
-        w.consts = take(4 * 4);
+        w.consts = take(8 * 4);
         w.partials = take((size_t)2 * kDiagBackwardBlocks * 4);
     }
     w.total = off;
@@ -823,9 +897,13 @@ int mfl_local_backward(const float *x, const float *img, const float *cd, const 
                           (uint32_t *)(base + ws.groups), st);
         if (rc) return rc;
         float *consts = (float *)(base + ws.consts), *P = (float *)(base + ws.psum), *Q = (float *)(base + ws.qsum);
-        float *dxp = (float *)(base + ws.xp2), *partials = (float *)(base + ws.partials);
+        float *dxp = (float *)(base + ws.xp2), *partials = (float *)(base + ws.partials);   // (dxp: 64-bit elements)
+        const size_t n = (size_t)B * C * dg.L;
         hipLaunchKernelGGL(diag_backward_consts_kernel, dim3(1), dim3(64), 0, st, consts);
-        MFL_CHECK_HIP(hipMemsetAsync(dxp, 0, diag_padded_floats(dg) * 4, st));
+        hipLaunchKernelGGL(diag_backward_absmax_kernel, dim3(grid_for(n) < 1024 ? grid_for(n) : 1024), dim3(kThreads), 0, st, dy, x, n,
+                           img, (size_t)B * 3 * dg.L, consts);
+        hipLaunchKernelGGL(diag_backward_scale_kernel, dim3(1), dim3(64), 0, st, pos_w, col_w, k, consts);
+        MFL_CHECK_HIP(hipMemsetAsync(dxp, 0, diag_padded_floats(dg) * 8, st));
         DiagArgs da{};
         da.g = dg;
         diag_lds(dg, da);
@@ -842,12 +920,12 @@ int mfl_local_backward(const float *x, const float *img, const float *cd, const 
         da.pos_w = pos_w; da.col_w = col_w; da.y = nullptr;
         da.unary = dy;
         da.qp_out = dxp;
+        da.aw = consts + 4;                       // the scatter's fixed-point scale
         rc = dispatch_diag(da, 3, st);
         if (rc) return rc;
-        const size_t n = (size_t)B * C * dg.L;
         const int blocks = grid_for(n) < kDiagBackwardBlocks ? grid_for(n) : kDiagBackwardBlocks;
-        hipLaunchKernelGGL(diag_backward_finish_kernel, dim3(blocks), dim3(kThreads), 0, st, dy, x, P, Q, dxp + dg.FS, pos_w,
-                           col_w, dx, partials, B * C, H, W, dg.Hp, dg.Wp, dg.p0);
+        hipLaunchKernelGGL(diag_backward_finish_kernel, dim3(blocks), dim3(kThreads), 0, st, dy, x, P, Q, (const long long *)dxp + dg.FS, consts,
+                           pos_w, col_w, dx, partials, B * C, H, W, dg.Hp, dg.Wp, dg.p0);
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kThreads), 0, st, partials, blocks, dparams);
         return (int)hipGetLastError();
     }
@@ -1073,6 +1151,21 @@ int mfl_argmax_labels(const float *logq, unsigned char *labels, int B, int C, in
     const size_t n = (size_t)B * H * W;
     hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0,
                        (hipStream_t)stream, logq, labels, B, C, H, W);
+    return (int)hipGetLastError();
+}
+
+int mfl_iou_counts(const unsigned char *pred, const unsigned char *target, unsigned long long *counts, size_t n, int C,
+                   mfl_stream_t stream)
+{
+    if (!pred || !target || !counts || n == 0 || C <= 0 || C > 256) return MFL_ERR_INVALID_ARGUMENT;
+    hipStream_t st = (hipStream_t)stream;
+    MFL_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)3 * C * sizeof(unsigned long long), st));
+    // each workgroup's 32-bit histogram counts at most 2^32 - 1 pixels: at least n / 2^31 workgroups
+    size_t blocks = (n + (size_t)kThreads * 64 - 1) / ((size_t)kThreads * 64);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    if (n / blocks >= (1ull << 31)) return MFL_ERR_TOO_LARGE;
+    hipLaunchKernelGGL(iou_counts_kernel, dim3((unsigned)blocks), dim3(kThreads), (size_t)3 * C * 4, st, pred, target, counts, n, C);
     return (int)hipGetLastError();
 }
 

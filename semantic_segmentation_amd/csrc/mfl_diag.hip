@@ -15,7 +15,7 @@
 // consecutive lanes = consecutive pixels) for the fused normalise step or the plain product.
 // The backward reuses the machinery transposed: D = dy * x enters through LDS into the accumulator
 // registers, and per (channel, tap) a lane sums what its k pixels send to the shared element and
-// adds it to the gradient planes with one float atomic (tap_scatter).
+// adds it to the gradient planes with one 64-bit fixed-point integer atomic (tap_scatter).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -237,7 +237,8 @@ __device__ __forceinline__ uint32_t rec_word(uint32_t recv, int j)
 template <int CH, int KS, int NGW, int NCS, bool BWD>
 struct Loop {
     using Cfg = DiagCfg<CH, KS, NGW, NCS>;
-    float *scatter_out;                     // BWD: FS floats before the image's zeroed padded gradient planes
+    unsigned long long *scatter_out;        // BWD: FS elements before the image's zeroed padded planes of 64-bit fixed-point sums
+    float fscale;                           // BWD: the fixed-point scale (a power of two)
     int C, ci;                              // BWD: channels, this wave's channel split
     DiagState<CH, KS, NGW, NCS> &st;
     __amdgpu_buffer_rsrc_t rsrc;
@@ -402,23 +403,24 @@ struct Loop {
 
     // Backward of one tap (the transpose of tap()): st.acc holds D = dy * x of the lane's pixels; what
     // the k pixels of a side send to their shared element is summed and added to the gradient planes
-    // with one float atomic per lane (64 consecutive floats per wave).  A flagged side splits the sum
+    // with one 64-bit fixed-point integer atomic per lane (fixed_point_add: the sums do not depend on the order).  A flagged side splits the sum
     // between the shared and the extra element by the same rule the gather reads them.
 #ifdef MFL_ABL_NO_ATOMIC
     // timing experiment: the sums are formed, the atomics replaced by a store no launch performs
-    __device__ __forceinline__ void unsafeAtomicAdd(float *p, float v) const { if (v == 1234.5678f) *p = v; }
-#endif
+    __device__ __forceinline__ void scatter_add(unsigned long long *p, float v) const { if (v == 1234.5678f) *p = 1; }
+#else
     // (lanes whose pixels are all outside the image hold D = 0: they send nothing)
-    __device__ __forceinline__ void scatter_add(float *p, float v) const
+    __device__ __forceinline__ void scatter_add(unsigned long long *p, float v) const
     {
-        if (v != 0.f) unsafeAtomicAdd(p, v);
+        if (v != 0.f) fixed_point_add(p, v, fscale);
     }
+#endif
     template <int SA>
     __device__ __forceinline__ void tap_scatter(const float (&w)[KS])
     {
         const uint32_t rec_new = request_record();
         const uint32_t hdr = rec_word(rec_use, 2 * CH);
-        float *base = scatter_out + lane;
+        unsigned long long *base = scatter_out + lane;
         constexpr int NA = KS - SA;
         auto threshold = [&](int x0) { return x0 + 63 > W - 1 ? W - x0 : (x0 < KS - 1 ? -x0 : 64); };
 #pragma unroll
@@ -684,7 +686,7 @@ diag_kernel(DiagGeom g, int epi_rows, int tail_per_group, const float *__restric
             __syncthreads();
         }
     }
-    Loop<CH, KS, NGW, NCS, MODE == 3> loop{qp_out + img_off, C, ci, st, rsrc,
+    Loop<CH, KS, NGW, NCS, MODE == 3> loop{reinterpret_cast<unsigned long long *>(qp_out) + img_off, MODE == 3 ? aw[0] : 0.f, C, ci, st, rsrc,
                                            table + diag_record_index(g, beta, live ? gamma : 0, 0, ci), groups, irsrc, lds,
                                            pw, cw, g.ngroups, g.TB, g.NCS * g.RECW, g.RECW, g.p0, Wp, W, g.gap * 4, gi,
                                            lane, live, dbg};

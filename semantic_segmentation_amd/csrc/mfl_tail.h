@@ -9,6 +9,18 @@
 
 namespace mfl {
 
+// Order-free accumulation of the backward scatter: a contribution v is added as the integer
+// round(v * scale) with a 64-bit integer atomic (integer sums do not depend on the order of the adds, so the
+// gradient is reproducible bit for bit; float atomics are not).  scale is a power of two chosen by the
+// host side so that |v * scale| < 2^50 for every contribution: 1.5 * 2^52 + v * scale is then exact in
+// double and its low mantissa bits are the rounded integer in two's complement.
+__device__ __forceinline__ void fixed_point_add(unsigned long long *p, float v, float scale)
+{
+    const double d = __builtin_fma((double)v, (double)scale, 6755399441055744.0);
+    const long long q = __builtin_bit_cast(long long, d) - 0x4338000000000000LL;
+    atomicAdd(p, (unsigned long long)q);
+}
+
 // The few pixels of a nearly empty last b-block (DiagGeom::tail_lanes) that the diagonal kernels
 // leave out, computed by extra workgroups at the end of the same launch (they fill the CUs that
 // the last round of regular workgroups leaves idle).  One wave per (image, group, chunk of 4 tail pixels); thread = (pixel, one of 16 channel
@@ -105,7 +117,9 @@ __device__ __forceinline__ void diag_tail_block(const DiagGeom &g, float *tail_l
         }
         if constexpr (MODE == 3) qv[j] = (valid && c < C) ? qv[j] * uv[j] : 0.f;   // D = dy * x
     }
-    float *grad_b = qp_out + img_off + g.FS;
+    // MODE 3: qp_out holds 64-bit fixed-point sums (same element indices), aw[0] the scale
+    unsigned long long *grad_b = reinterpret_cast<unsigned long long *>(qp_out) + img_off + g.FS;
+    const float fscale = MODE == 3 ? aw[0] : 0.f;
 #pragma unroll 4
     for (int t = 0; t < K; ++t) {
         const float wv = wt[p * K + t];
@@ -115,7 +129,7 @@ __device__ __forceinline__ void diag_tail_block(const DiagGeom &g, float *tail_l
 #ifdef MFL_ABL_NO_TAIL_ATOMIC
             if constexpr (MODE == 3) acc[j] += wv * qv[j] * (float)(tab[rr[j]] + ys * Wp + xs);
 #else
-            if constexpr (MODE == 3) unsafeAtomicAdd(grad_b + tab[rr[j]] + ys * Wp + xs, wv * qv[j]);
+            if constexpr (MODE == 3) { if (wv * qv[j] != 0.f) fixed_point_add(grad_b + tab[rr[j]] + ys * Wp + xs, wv * qv[j], fscale); }
 #endif
             else acc[j] = fmaf(wv, in_b[tab[rr[j]] + ys * Wp + xs], acc[j]);
             lp[j] += qL;

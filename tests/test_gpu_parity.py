@@ -194,6 +194,62 @@ def test_meanfield_vs_oracle(shape, mode, S, oracle):
         assert decided.mean() > 0.5
 
 
+def test_backward_full_512_image_vs_oracle_and_bitwise_reproducible(S, oracle):
+    """21 labels, 512x512, 7x7, batch 4 (one GPU's share of the training configuration): image 2 of the batch
+    against the C oracle, and the whole dx bit for bit equal between two runs (the scatter is summed in
+    64-bit fixed point, so the order of the adds does not matter)."""
+    shape = (4, 21, 512, 512, 7)
+    x, img, dy = make_inputs(shape, 21)
+    pw, cw = scalar(-0.004), scalar(-0.003)
+    dx1, dp1, _ = S.ops.local_backward(dev(x), pw, cw, 7, dev(dy), image=dev(img))
+    dx2, dp2, _ = S.ops.local_backward(dev(x), pw, cw, 7, dev(dy), image=dev(img))
+    assert torch.equal(dx1, dx2) and torch.equal(dp1, dp2)
+    rdx, rdpw, rdcw = oracle.local_backward(x[2:3], -0.004, -0.003, 7, dy[2:3], img=img[2:3])
+    assert_close(host(dx1[2:3]), rdx, RTOL, "dx of image 2")
+    alone = S.ops.local_backward(dev(x[2:3]), pw, cw, 7, dev(dy[2:3]), image=dev(img[2:3]))
+    assert abs(float(alone[1][0]) - rdpw) <= 2e-4 * abs(rdpw) and abs(float(alone[1][1]) - rdcw) <= 2e-4 * abs(rdcw)
+    # strict elementwise relative error where the gradient is not tiny
+    big = np.abs(rdx) > 1e-3 * np.abs(rdx).max()
+    assert (np.abs(host(dx1[2:3]) - rdx)[big] / np.abs(rdx)[big]).max() < 1e-4
+
+
+def test_backward_fixed_point_scale_follows_the_data(S, oracle):
+    """The fixed-point scale of the scatter is derived from max|dy*x| and max|img|: gradients 1e6 times larger or
+    smaller keep the same relative accuracy."""
+    shape = (1, 8, 70, 96, 5)
+    x, img, dy = make_inputs(shape, 22)
+    for f in (1e-6, 1.0, 1e6):
+        dx, _, _ = S.ops.local_backward(dev(x), scalar(0.3), scalar(-0.7), 5, dev(dy * np.float32(f)), image=dev(img))
+        rdx, _, _ = oracle.local_backward(x, 0.3, -0.7, 5, dy * np.float32(f), img=img)
+        assert_close(host(dx), rdx, RTOL, f"dx, dy scaled by {f}")
+
+
+def test_iou_counts_and_reference_conventions(S):
+    """Per-class counters on device against the reference's loop (AdvancedModel.py:469-483) restated with
+    numpy: exact integers; IoU -1 for an absent class, class 0 skipped unless asked for, 255 = void."""
+    rng = np.random.default_rng(3)
+    C = 21
+    target = rng.integers(0, 19, size=(3, 96, 130)).astype(np.uint8)          # classes 19, 20 never appear
+    target[rng.random(target.shape) < 0.05] = 255
+    pred = np.where(rng.random(target.shape) < 0.7, target, rng.integers(0, 19, size=target.shape)).astype(np.uint8)
+    pred[pred == 255] = 3
+    counts = host(S.ops.iou_counts(dev(pred), dev(target), C))
+    for c in range(C):
+        assert counts[0, c] == np.sum((pred == c) & (target == c))
+        assert counts[1, c] == np.sum(pred == c) and counts[2, c] == np.sum(target == c)
+    for bg in (False, True):
+        want = np.zeros(C, np.float32)
+        for c in range(0 if bg else 1, C):
+            inter = np.sum((pred == c) & (target == c))
+            union = np.sum(pred == c) + np.sum(target == c) - inter
+            want[c] = -1 if union == 0 else inter / union
+        got = host(S.ops.intersection_over_union(dev(pred), dev(target), C, include_background=bg))
+        assert np.allclose(got, want, rtol=1e-6, atol=0)
+        m = want[want > 0]
+        assert abs(S.ops.mean_intersection_over_union(dev(pred), dev(target), C, bg) - (m.mean() if len(m) else 0)) < 1e-6
+    assert np.array_equal(host(S.ops.iou_counts(dev(pred), dev(target), C)), counts)       # order-free integer sums
+
+
 def _loop_backward(S, d, K, affine):
     opt = lambda a: None if a is None else dev(a)
     return S.ops.meanfield_backward(dev(d["unary"]), dev(d["img"]), scalar(d["pw"]), scalar(d["cw"]), int(d["k"]), K,
