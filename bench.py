@@ -309,6 +309,24 @@ def run_training(job, key, steps, warmup):
             "allreduce_floats": int(sum(gr.numel() for gr in grads))}
 
 
+def run_reference_default(job):
+    """The one configuration the reference ships (AdvancedModel.py:135-137): 21 labels, 64x64, 50x50 window,
+    one image.  Whole-call times (set-up included), HIP events, median of 5."""
+    import semantic_segmentation_amd as S
+    dev = job.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    unary = 2 * torch.randn(1, 21, 64, 64, generator=g, device=dev)
+    img = torch.randn(1, 3, 64, 64, generator=g, device=dev)
+    pw = torch.tensor([POS_W], device=dev)
+    cw = torch.tensor([COL_W], device=dev)
+    fwd = lambda: S.ops.local_forward(unary, pw, cw, 50, image=img)
+    mf = lambda: S.ops.meanfield_forward(unary, img, pw, cw, 50, 1)
+    fwd(), mf()
+    return {"workload": "the reference's shipped model: 21 labels, 64x64, 50x50 window, batch 1 (AdvancedModel.py:135-137)",
+            "local_forward_ms": round(event_ms(fwd), 4), "meanfield_1_iteration_ms": round(event_ms(mf), 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -339,6 +357,7 @@ def main():
                     "workload": r["config"]["workload"], "value": r["value"], "unit": "iter*Mpixel/s",
                     "ms_per_step": r["ms_per_step"], "steps": st, "launch_ms": r["roofline"]["launch_ms"],
                     "hbm_frac": r["roofline"]["frac"], "valu_frac": r["roofline"]["valu"]["frac"]}
+            others["reference_default_k50"] = run_reference_default(job)
     if job.rank == 0:
         line = {"metric": "mean-field iter*Mpixel/s (node)", "value": main_res["value"], "unit": "iter*Mpixel/s",
                 "n_gpus": job.world, "steps": args.steps, "warmup": args.warmup,

@@ -44,6 +44,10 @@ using namespace mfl;
 #ifndef MFL_M0_WAVES
 #define MFL_M0_WAVES 2
 #endif
+// ... and the plain window-sum kernels (modes 1, 2)
+#ifndef MFL_M12_WAVES
+#define MFL_M12_WAVES 2
+#endif
 
 namespace {
 
@@ -337,7 +341,7 @@ weights_kernel(RingGeom rg, const F4 *__restrict__ ip4, const float *__restrict_
 
 // MODE 0: fused mean-field update   MODE 1: y = x * window sums   MODE 2: y = window sums
 template <int CH, int KS, int NGW, int NCS, int MODE>
-__global__ void __launch_bounds__(64 * NGW * NCS) __attribute__((amdgpu_waves_per_eu(MODE == 0 ? MFL_M0_WAVES : 4)))
+__global__ void __launch_bounds__(64 * NGW * NCS) __attribute__((amdgpu_waves_per_eu(MODE == 0 ? MFL_M0_WAVES : MFL_M12_WAVES)))
 ring_kernel(RingGeom rg, int lds_floats, int tail_per_group, const float *__restrict__ xp, const F4 *__restrict__ ip4,
             const uint32_t *__restrict__ table, const float *__restrict__ wtab, const float *__restrict__ pos_w, const float *__restrict__ col_w,
             const float *__restrict__ unary, const float *__restrict__ aw, const float *__restrict__ ab,
@@ -557,13 +561,13 @@ ring_kernel(RingGeom rg, int lds_floats, int tail_per_group, const float *__rest
                     mv = fmaxf(mv, u[v]);
                 }
                 mv = fmaxf(mv, other_half(mv));
-                // Q_{t+1} = exp(u - mv) / sum: the exponentials of the sum are reused for the output
-                float e[NV], sv = 0.f;
+                // Q_{t+1} = exp(u - mv) / sum (the exponentials are evaluated again for the output rather than
+                // held in registers across the exchange)
+                float sv = 0.f;
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     u[v] -= mv;
-                    e[v] = __expf(u[v]);
-                    sv += e[v];
+                    sv += __expf(u[v]);
                 }
                 sv += other_half(sv);
                 const float rsv = 1.f / sv;
@@ -574,7 +578,7 @@ ring_kernel(RingGeom rg, int lds_floats, int tail_per_group, const float *__rest
 #endif
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, e[v] * rsv), rqo,
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, __expf(u[v]) * rsv), rqo,
                                                           (int)(sq + (uint32_t)((8 * (v / 4) + (v % 4)) * plane4)), 0, 0);
                 if (logq) {
                     const float lsv = __logf(sv);

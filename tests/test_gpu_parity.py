@@ -170,6 +170,16 @@ def test_tensor_mode_equals_image_mode(shape, S):
     assert abs(got - float(dpb[1])) <= 1e-4 * abs(float(dpb[1])) + 1e-5
 
 
+def strict_rel_err_on_marginals(logq, ref_logq):
+    """max |Q - Q_ref| / Q_ref over the marginals Q = exp(logq) with Q_ref > 1e-6: the elementwise
+    relative figure (no tensor-scale floor).  It equals the absolute error of the logit, so it grows with
+    the size of the messages: fp32 sums of K*C terms hold it below 1e-4 for potentials of the reference's
+    initial scale (|weights| <= 0.005, LocalConvolution.py:55-57)."""
+    q, qr = np.exp(np.asarray(logq, np.float64)), np.exp(np.asarray(ref_logq, np.float64))
+    m = qr > 1e-6
+    return float((np.abs(q - qr)[m] / qr[m]).max())
+
+
 @pytest.mark.parametrize("shape", [SHAPES[0], SHAPES[1], SHAPES[2], SHAPES[3], SHAPES[5]] + DIAG_SHAPES)
 @pytest.mark.parametrize("mode", ["plain", "compat", "affine+compat"])
 def test_meanfield_vs_oracle(shape, mode, S, oracle):
@@ -186,12 +196,30 @@ def test_meanfield_vs_oracle(shape, mode, S, oracle):
         ref = oracle.meanfield_forward(unary, img, -0.004, -0.003, k, iters, aw, ab, compat)
         assert_close(lq, ref, RTOL, f"logq {mode} iters={iters}")
         assert np.allclose(np.exp(lq.astype(np.float64)).sum(1), 1.0, atol=1e-5)
+        assert strict_rel_err_on_marginals(lq, ref) < RTOL, f"marginals {mode} iters={iters}"
         # label maps: identical wherever the top-2 margin exceeds the tolerance
         labels = host(S.ops.argmax_labels(dev(lq)))
         srt = np.sort(ref, axis=1)
         decided = (srt[:, -1] - srt[:, -2]) > RTOL * (1 + np.abs(srt[:, -1]))
         assert (labels[decided] == ref.argmax(1)[decided]).all()
         assert decided.mean() > 0.5
+
+
+def test_config4_full_image_meanfield_step_vs_oracle(S, oracle):
+    """19 labels, 1024x2048, 11x11 (BASELINE config 4): fused mean-field steps of one full image (stream
+    kernels, weight table, MFMA label product) against the C oracle, logits and marginals."""
+    shape = (1, 19, 1024, 2048, 11)
+    unary, img, _ = make_inputs(shape, 31)
+    rng = np.random.default_rng(32)
+    compat = ((1 - np.eye(19)) + 0.01 * rng.standard_normal((19, 19))).astype(np.float32)
+    lq = host(S.ops.meanfield_forward(dev(unary), dev(img), scalar(-0.004), scalar(-0.003), 11, 2, None, None, dev(compat)))
+    ref = oracle.meanfield_forward(unary, img, -0.004, -0.003, 11, 2, None, None, compat)
+    assert_close(lq, ref, RTOL, "logq")
+    assert strict_rel_err_on_marginals(lq, ref) < RTOL
+    labels = host(S.ops.argmax_labels(dev(lq)))
+    srt = np.sort(ref, axis=1)
+    decided = (srt[:, -1] - srt[:, -2]) > RTOL * (1 + np.abs(srt[:, -1]))
+    assert (labels[decided] == ref.argmax(1)[decided]).all()
 
 
 def test_backward_full_512_image_vs_oracle_and_bitwise_reproducible(S, oracle):
