@@ -748,6 +748,10 @@ int scratch_pointer(void **out)
 
 namespace mfl {
 size_t loop_backward_workspace_bytes(int B, int C, int H, int W, int k, int iters);   // mfl_loop_backward.hip
+bool label_step_supported(int C);                                                    // mfl_label_step.hip
+bool label_step_fits(int B, int C, int H, int W, int q_pad_k);
+int launch_label_step(const float *msg, const float *aw, const float *ab, const float *compat, const float *unary, float *logq,
+                      float *q, int q_pad_k, int B, int C, int H, int W, hipStream_t st);
 }
 
 // ------------------------------------------------------------------ C ABI
@@ -1100,6 +1104,13 @@ static int meanfield_forward_impl(const float *unary, const float *img, const fl
             const GatherArgs ga{g, false, tab_lds, qa, ip4, nullptr, tab, pos_w, col_w};
             rc = dispatch_local_forward(cc, ga, msg, st);
             if (rc) return rc;
+            if (compat && mfl::label_step_supported(C) && mfl::label_step_fits(B, C, H, W, k)) {
+                // label product on the matrix cores, fused with the affine and the normalise step
+                rc = mfl::launch_label_step(msg, affine_w, affine_b, compat, unary, lq, qb, k, B, C, H, W, st);
+                if (rc) return rc;
+                float *t = qa; qa = qb; qb = t;
+                continue;
+            }
             if (affine_w || compat) {
                 static bool raised = false;     // more than the default 64 KB of dynamic LDS past 256 labels
                 if (!raised) {

@@ -205,6 +205,42 @@ def test_meanfield_vs_oracle(shape, mode, S, oracle):
         assert decided.mean() > 0.5
 
 
+@pytest.mark.parametrize("mode", ["compat", "affine+compat"])
+def test_150_labels_128x128_vs_oracle(mode, S, oracle):
+    """150 labels at 128x128 (H*W > C*K, the regime of the 512x512 configuration): gather in channel chunks,
+    then the fused label step with the 150x150 product on the matrix cores, against the C oracle."""
+    shape = (1, 150, 128, 128, 7)
+    C = 150
+    unary, img, _ = make_inputs(shape, 41)
+    rng = np.random.default_rng(42)
+    compat = ((1 - np.eye(C)) + 0.01 * rng.standard_normal((C, C))).astype(np.float32) / 8
+    aw = (1 + 0.2 * rng.standard_normal((1, C, 128, 128))).astype(np.float32) if "affine" in mode else None
+    ab = (0.1 * rng.standard_normal((1, C, 128, 128))).astype(np.float32) if "affine" in mode else None
+    opt = lambda a: None if a is None else dev(a)
+    for iters in (1, 3):
+        lq = host(S.ops.meanfield_forward(dev(unary), dev(img), scalar(-0.004), scalar(-0.003), 7, iters, opt(aw), opt(ab), dev(compat)))
+        ref = oracle.meanfield_forward(unary, img, -0.004, -0.003, 7, iters, aw, ab, compat)
+        assert_close(lq, ref, RTOL, f"logq iters={iters}")
+        assert strict_rel_err_on_marginals(lq, ref) < RTOL
+
+
+def test_150_labels_full_size_properties(S):
+    """150 labels, 512x512 (BASELINE config 5 image size), batch 2: marginals sum to one, and an image's result
+    does not depend on what else is in the batch."""
+    shape = (2, 150, 512, 512, 7)
+    C = 150
+    g = torch.Generator(device="cuda").manual_seed(5)
+    unary = 2 * torch.randn(shape[:4], device="cuda", generator=g)
+    img = torch.randn(2, 3, 512, 512, device="cuda", generator=g)
+    compat = (1 - torch.eye(C, device="cuda")) / 8
+    pw, cw = scalar(-0.004), scalar(-0.003)
+    lq = S.ops.meanfield_forward(unary, img, pw, cw, 7, 2, None, None, compat)
+    assert torch.isfinite(lq).all()
+    assert (torch.exp(lq.double()).sum(1) - 1).abs().max() < 1e-5
+    alone = S.ops.meanfield_forward(unary[1:2], img[1:2], pw, cw, 7, 2, None, None, compat)
+    assert torch.equal(alone[0], lq[1])
+
+
 def test_config4_full_image_meanfield_step_vs_oracle(S, oracle):
     """19 labels, 1024x2048, 11x11 (BASELINE config 4): fused mean-field steps of one full image (stream
     kernels, weight table, MFMA label product) against the C oracle, logits and marginals."""
