@@ -187,6 +187,28 @@ int mfl_meanfield_forward_noalloc(const float *unary, const float *img, const fl
 int mfl_argmax_labels(const float *logq, unsigned char *labels, int B, int C, int H, int W, mfl_stream_t stream);
 
 /*
+ * The reference's label-context block and the combine step behind it, fused:
+ *   a      = la_w * t + la_b                  local_activation_function,  AdvancedModel.py:138, 223
+ *   c      = ga_w * Conv2d(L -> L*M, ks x ks, pad ks/2)(a) + ga_b
+ *                                             global_convolution_layer / global_activation_function,
+ *                                             AdvancedModel.py:143-145, 232-233
+ *   smooth = min over the M mixtures of c     BlockMinPooling, AdvancedModel.py:32-35, 150, 235
+ *   logq   = LogSoftmax(log_softmax(unary) - smooth)                       AdvancedModel.py:242-244
+ * i.e. DPNModel.forward phases 3 and 4 behind the local convolution.  The convolution runs as an implicit GEMM
+ * on the fp32 matrix instructions.
+ *   t, unary, smooth, logq: [B][L][H][W]      (smooth, logq: outputs, either may be NULL, not both)
+ *   la_w, la_b: [L][H][W] or NULL (both or neither)     ga_w, ga_b: [L*M][H][W] or NULL (both or neither)
+ *   conv_w: [L*M][L][ks][ks]   conv_b: [L*M] or NULL
+ * L <= 32, M <= 5, ks odd and <= 15 (the reference: L = 21, M = 5, ks = 9).
+ * Workspace: mfl_label_context_workspace_bytes().
+ */
+size_t mfl_label_context_workspace_bytes(int B, int L, int M, int H, int W, int ks);
+int mfl_label_context_forward(const float *t, const float *la_w, const float *la_b, const float *conv_w,
+                              const float *conv_b, const float *ga_w, const float *ga_b, const float *unary,
+                              float *smooth, float *logq, int B, int L, int M, int H, int W, int ks, void *workspace,
+                              size_t workspace_bytes, mfl_stream_t stream);
+
+/*
  * Per-class pixel counts behind the reference's intersection-over-union
  * (DPNModel.calc_intersection_over_union, AdvancedModel.py:448-485):
  *   counts[0][c] = #(pred == c and target == c)    intersection

@@ -106,3 +106,32 @@ class MeanFieldLocal(nn.Module):
             logq = functional.log_softmax(ls_unary - msg, dim=1)
             q = torch.exp(logq)
         return logq
+
+
+class LabelContext(nn.Module):
+    """The reference's label-context block and combine step (DPNModel.forward phases 3-4, AdvancedModel.py:223,
+    232-244) on the library's fused kernel.  Submodule names and parameter shapes are the reference's
+    (AdvancedModel.py:138, 143-145), so the matching entries of a DPNModel state dict load here.
+    Inference only: the kernel has no backward."""
+
+    def __init__(self, in_height: int, in_width: int, num_labels: int = 21, num_mixture_filters: int = 5,
+                 kernel_size: int = 9):
+        super().__init__()
+        self.num_labels, self.num_mixture_filters = num_labels, num_mixture_filters
+        channels = num_labels * num_mixture_filters
+        self.local_activation_function = LinearActivation(num_labels, in_height, in_width)
+        self.global_convolution_layer = nn.Conv2d(num_labels, channels, kernel_size=(kernel_size, kernel_size),
+                                                  padding=(kernel_size // 2, kernel_size // 2))
+        self.global_activation_function = LinearActivation(channels, in_height, in_width)
+
+    def forward(self, local_output: torch.Tensor, unary: torch.Tensor, want_smooth: bool = False):
+        if torch.is_grad_enabled() and (local_output.requires_grad or unary.requires_grad
+                                        or any(p.requires_grad for p in self.parameters())):
+            raise RuntimeError("LabelContext runs without gradients (wrap the call in torch.no_grad())")
+        conv = self.global_convolution_layer
+        return ops.label_context_forward(local_output, conv.weight, unary, conv_b=conv.bias,
+                                         la_w=self.local_activation_function.weight,
+                                         la_b=self.local_activation_function.bias,
+                                         ga_w=self.global_activation_function.weight,
+                                         ga_b=self.global_activation_function.bias,
+                                         mixtures=self.num_mixture_filters, want_smooth=want_smooth)

@@ -141,6 +141,43 @@ def argmax_labels(logq: torch.Tensor) -> torch.Tensor:
     return labels
 
 
+def label_context_forward(t, conv_w, unary, conv_b=None, la_w=None, la_b=None, ga_w=None, ga_b=None, mixtures=None,
+                          want_smooth=False):
+    """DPNModel.forward phases 3-4 behind the local convolution (AdvancedModel.py:223, 232-244): per-pixel affine,
+    Conv2d(L -> L*M, ks x ks, pad ks//2), per-pixel affine, min over the M mixtures, then
+    LogSoftmax(log_softmax(unary) - smooth).  Returns logq, or (logq, smooth) with want_smooth."""
+    _lib.require_device(t, conv_w, unary, conv_b, la_w, la_b, ga_w, ga_b)
+    t, conv_w, unary, conv_b = _c(t), _c(conv_w), _c(unary), _c(conv_b)
+    la_w, la_b, ga_w, ga_b = _c(la_w), _c(la_b), _c(ga_w), _c(ga_b)
+    B, L, H, W = t.shape
+    if conv_w.dim() != 4 or conv_w.shape[1] != L or conv_w.shape[2] != conv_w.shape[3] or conv_w.shape[0] % L:
+        raise RuntimeError(f"conv_w must be [L*M, {L}, ks, ks], got {tuple(conv_w.shape)}")
+    M, ks = conv_w.shape[0] // L, conv_w.shape[2]
+    if mixtures is not None and mixtures != M:
+        raise RuntimeError(f"conv_w holds {M} mixtures, expected {mixtures}")
+    if unary.shape != t.shape:
+        raise RuntimeError(f"unary must be {tuple(t.shape)}, got {tuple(unary.shape)}")
+    if (la_w is None) != (la_b is None) or (ga_w is None) != (ga_b is None):
+        raise ValueError("affine weight and bias must be given together")
+    if la_w is not None and (la_w.numel() != L * H * W or la_b.numel() != L * H * W):
+        raise RuntimeError("la_w / la_b must hold L*H*W elements")
+    if ga_w is not None and (ga_w.numel() != L * M * H * W or ga_b.numel() != L * M * H * W):
+        raise RuntimeError("ga_w / ga_b must hold L*M*H*W elements")
+    if conv_b is not None and conv_b.numel() != L * M:
+        raise RuntimeError("conv_b must hold L*M elements")
+    n = int(lib.mfl_label_context_workspace_bytes(B, L, M, H, W, ks))
+    if n == 0:
+        raise ValueError(f"unsupported label-context problem: L={L} (<= 32), M={M} (<= 5), ks={ks} (odd, <= 15)")
+    logq = torch.empty_like(t)
+    smooth = torch.empty_like(t) if want_smooth else None
+    with torch.cuda.device(t.device):
+        ws = torch.empty(n, dtype=torch.uint8, device=t.device)
+        _lib.check(lib.mfl_label_context_forward(ptr(t), ptr(la_w), ptr(la_b), ptr(conv_w), ptr(conv_b), ptr(ga_w), ptr(ga_b),
+                                                 ptr(unary), ptr(smooth), ptr(logq), B, L, M, H, W, ks, ptr(ws), n,
+                                                 stream_of(t)), "mfl_label_context_forward")
+    return (logq, smooth) if want_smooth else logq
+
+
 def iou_counts(pred: torch.Tensor, target: torch.Tensor, num_labels: int) -> torch.Tensor:
     """int64 [3, num_labels]: per class the pixels in both, in the prediction, in the target
     (the counts behind DPNModel.calc_intersection_over_union, AdvancedModel.py:448-485).

@@ -83,6 +83,56 @@ def test_dpn_phase2_and_combine_golden(S):
     assert_close(host(out), d["phase4"], 2e-4, "phase4")   # includes MIOpen's 9x9 convolution
 
 
+def test_label_context_tail_golden(S):
+    """a5 -> a8 -> a6 -> a7 (AdvancedModel.py:223-244) in the library's fused kernel (9x9 convolution on the
+    fp32 matrix instructions, no vendor convolution): the reference's tail outputs `smooth` and `out`."""
+    d = load(golden_files("tail")[0])
+    out, smooth = S.ops.label_context_forward(dev(d["t"]), dev(d["conv_w"]), dev(d["unary"]), conv_b=dev(d["conv_b"]),
+                                              la_w=dev(d["la_w"]), la_b=dev(d["la_b"]), ga_w=dev(d["ga_w"]),
+                                              ga_b=dev(d["ga_b"]), mixtures=int(d["mixtures"]), want_smooth=True)
+    assert_close(host(smooth), d["smooth"], RTOL, "smooth")
+    assert_close(host(out), d["out"], RTOL, "out")
+
+
+def test_dpn_phases_2_3_4_on_the_library_alone(S):
+    """DPNModel.forward phases 2, 3 and 4 (AdvancedModel.py:216-244) from the unary on, with the reference's own
+    50x50 window: local operator, then the fused label-context kernel; no stock convolution involved."""
+    d = load(golden_files("dpn")[0])
+    k, M = int(d["k"]), int(d["mixtures"])
+    unary, img = dev(d["unary"]), dev(d["img"])
+    msg = S.ops.local_forward(unary, scalar(d["pw"]), scalar(d["cw"]), k, image=img)
+    out, smooth = S.ops.label_context_forward(msg, dev(d["conv_w"]), unary, conv_b=dev(d["conv_b"]), la_w=dev(d["la_w"]),
+                                              la_b=dev(d["la_b"]), ga_w=dev(d["ga_w"]), ga_b=dev(d["ga_b"]), mixtures=M,
+                                              want_smooth=True)
+    assert_close(host(torch.log_softmax(smooth, dim=1)), d["phase3"], RTOL, "phase3")
+    assert_close(host(out), d["phase4"], RTOL, "phase4")
+
+
+@pytest.mark.parametrize("B,L,M,H,W,ks", [(2, 21, 5, 40, 70, 9), (1, 7, 2, 33, 31, 3), (1, 32, 1, 20, 65, 5)])
+def test_label_context_vs_float64_composition(B, L, M, H, W, ks, S):
+    """The fused kernel against the same chain composed in float64 on the host (conv2d, affine, min, softmax),
+    on sizes with ragged row tiles, with and without the optional affines and bias."""
+    g = torch.Generator().manual_seed(77)
+    t = torch.randn(B, L, H, W, generator=g)
+    unary = 2 * torch.randn(B, L, H, W, generator=g)
+    conv_w = 0.05 * torch.randn(L * M, L, ks, ks, generator=g)
+    conv_b = 0.1 * torch.randn(L * M, generator=g)
+    la_w, la_b = 1 + 0.2 * torch.randn(1, L, H, W, generator=g), 0.1 * torch.randn(1, L, H, W, generator=g)
+    ga_w, ga_b = 1 + 0.2 * torch.randn(1, L * M, H, W, generator=g), 0.1 * torch.randn(1, L * M, H, W, generator=g)
+    for full in (True, False):
+        kw = dict(conv_b=conv_b, la_w=la_w, la_b=la_b, ga_w=ga_w, ga_b=ga_b) if full else {}
+        a = (la_w * t + la_b) if full else t
+        c = torch.nn.functional.conv2d(a.double(), conv_w.double(), conv_b.double() if full else None, padding=ks // 2)
+        if full:
+            c = ga_w.double() * c + ga_b.double()
+        smooth = c.reshape(B, M, L, H, W).min(dim=1).values
+        want = torch.log_softmax(torch.log_softmax(unary.double(), dim=1) - smooth, dim=1)
+        out, sm = S.ops.label_context_forward(t.cuda(), conv_w.cuda(), unary.cuda(), want_smooth=True,
+                                              **{n: v.cuda() for n, v in kw.items()})
+        assert_close(host(sm), smooth.numpy(), RTOL, f"smooth full={full}")
+        assert_close(host(out), want.numpy(), RTOL, f"logq full={full}")
+
+
 def test_tail_golden(S):
     d = load(golden_files("tail")[0])
     out, q = S.ops.combine_forward(dev(d["unary"]), dev(d["c"]), mixtures=int(d["mixtures"]), want_q=True)

@@ -57,3 +57,14 @@ def test_meanfield_module_parameters():
     assert m.compat.shape == (5, 5) and m.local_activation_function.weight.shape == (1, 5, 8, 8)
     with pytest.raises(ValueError):
         S.MeanFieldLocal(8, 8, 5, 3, iters=0)
+
+
+def test_label_context_module_mirrors_the_reference_state_dict_keys():
+    import semantic_segmentation_amd as S
+    m = S.LabelContext(8, 9, num_labels=4, num_mixture_filters=5)
+    keys = set(m.state_dict())
+    assert keys == {"local_activation_function.weight", "local_activation_function.bias",
+                    "global_convolution_layer.weight", "global_convolution_layer.bias",
+                    "global_activation_function.weight", "global_activation_function.bias"}
+    assert m.global_convolution_layer.weight.shape == (20, 4, 9, 9)
+    assert m.global_activation_function.weight.shape == (1, 20, 8, 9)
