@@ -97,8 +97,31 @@ def require_device(*tensors: torch.Tensor) -> None:
             raise RuntimeError(f"tensors on different devices: {dev} and {t.device}")
 
 
+_PLANS = {}          # (op, B, C, H, W, k, iters, device) -> workspace kept between calls (keep_plans(True))
+_KEEP_PLANS = False
+
+
+def keep_plans(enable: bool = True) -> None:
+    """Keep one workspace per (operation, problem size, device) alive between calls instead of taking a fresh
+    one from torch's allocator each time.  The library tags a workspace with the plan (address tables) it
+    holds and skips rebuilding them when it finds its own tag, which is only safe while nobody else writes
+    to that memory: a kept workspace guarantees it, a block handed back to the caching allocator does not
+    (so fresh workspaces get their tag cleared).  keep_plans(False) drops the kept workspaces."""
+    global _KEEP_PLANS
+    _KEEP_PLANS = bool(enable)
+    if not enable:
+        _PLANS.clear()
+
+
 def workspace(op: int, B: int, C: int, H: int, W: int, k: int, iters: int, device) -> torch.Tensor:
     n = int(lib.mfl_workspace_bytes(op, B, C, H, W, k, iters))
     if n == 0:
         raise ValueError(f"invalid problem size B={B} C={C} H={H} W={W} k={k}")
-    return torch.empty(n, dtype=torch.uint8, device=device)
+    key = (op, B, C, H, W, k, iters, str(device))
+    if _KEEP_PLANS and key in _PLANS:
+        return _PLANS[key]
+    ws = torch.empty(n, dtype=torch.uint8, device=device)
+    ws[:32].zero_()          # no plan tag: whatever this block held before is not trusted
+    if _KEEP_PLANS:
+        _PLANS[key] = ws
+    return ws

@@ -290,11 +290,43 @@ int backward_blocks(const Geom &g, int cc)
     return blocks_per_image(g) * ((g.C + cc - 1) / cc) * g.B;
 }
 
+// ---- plan tag ----------------------------------------------------------------------------------
+// The first 256 bytes of a workspace identify what the library last laid out in it: {magic, kernel family,
+// operation, B, C, H, W, k}.  The address tables depend on nothing else, so a call that finds its own tag
+// skips rebuilding them (the table kernels compare the tag on the device and return; no host read-back, no
+// state in the library).  Every call that uses the workspace writes its tag after its tables, so a call of
+// another operation or size invalidates the plan; a caller that writes to the workspace itself must clear
+// these bytes.
+struct PlanTag {
+    uint32_t v[8];
+};
+
+PlanTag make_tag(int family, int op, int B, int C, int H, int W, int k)
+{
+    return PlanTag{{0x4d464c31u, (uint32_t)family, (uint32_t)op, (uint32_t)B, (uint32_t)C, (uint32_t)H, (uint32_t)W, (uint32_t)k}};
+}
+
+__device__ __forceinline__ bool tag_matches(const uint32_t *__restrict__ tag, const PlanTag &want)
+{
+    bool same = true;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) same = same && tag[i] == want.v[i];
+    return same;
+}
+
+__global__ void stamp_tag_kernel(uint32_t *tag, PlanTag t)
+{
+    if (threadIdx.x < 8) tag[threadIdx.x] = t.v[threadIdx.x];
+}
+
+constexpr size_t kTagBytes = 256;
+
 Workspace carve(int op, const Geom &g, int cc)
 {
     Workspace w{};
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    take(kTagBytes);                                  // plan tag
     w.xp = take(padded_floats(g) * 4);
     w.ip4 = take(((size_t)g.B * g.plane + 64) * sizeof(F4));
     w.tab = take((size_t)g.CK * 4);
@@ -318,8 +350,10 @@ int check_common(const void *a, const void *b, int B, int C, int H, int W, int k
     return MFL_OK;
 }
 
-int launch_prepare(const Geom &g, const float *x, const float *img, float *xp, F4 *ip4, int *tab, hipStream_t st)
+int launch_prepare(void *workspace, const Geom &g, const float *x, const float *img, float *xp, F4 *ip4, int *tab, hipStream_t st)
 {
+    // (this family rebuilds its small offset table every call; its tag only invalidates other plans)
+    hipLaunchKernelGGL(stamp_tag_kernel, dim3(1), dim3(64), 0, st, (uint32_t *)workspace, make_tag(3, 0, g.B, g.C, g.H, g.W, g.k));
     if (x) {
         const size_t n = (size_t)g.B * g.C * g.plane;
         hipLaunchKernelGGL(pad_planes_kernel, dim3(pad_rows_grid((size_t)g.B * g.C * g.Hp)), dim3(kThreads), 0, st, x, xp, g.B * g.C, g.H, g.W,
@@ -401,8 +435,9 @@ unsigned long long *g_stamps = nullptr;   // diagnostic builds only: device buff
 constexpr int kDiagWeightLds = 120 * 1024;   // LDS budget of the double-buffered tap-weight table
 
 // Address table and weight-group list of the diagonal kernels, built on the device.
-__global__ void diag_table_kernel(DiagGeom g, uint32_t *__restrict__ table)
+__global__ void diag_table_kernel(DiagGeom g, uint32_t *__restrict__ table, const uint32_t *__restrict__ tag, PlanTag want)
 {
+    if (tag_matches(tag, want)) return;               // the workspace holds this plan already
     const size_t nrec = (size_t)g.NBB * g.NG * g.K * g.NCS;
     for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrec; r += (size_t)gridDim.x * blockDim.x) {
         const int ci = (int)(r % g.NCS);
@@ -415,18 +450,20 @@ __global__ void diag_table_kernel(DiagGeom g, uint32_t *__restrict__ table)
     }
 }
 
-__global__ void diag_groups_kernel(DiagGeom g, uint32_t *__restrict__ groups)
+__global__ void diag_groups_kernel(DiagGeom g, uint32_t *__restrict__ groups, const uint32_t *__restrict__ tag, PlanTag want)
 {
+    if (tag_matches(tag, want)) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) diag_groups(g, groups);
 }
 
 
-int launch_diag_table(const DiagGeom &g, uint32_t *table, uint32_t *groups, hipStream_t st)
+int launch_diag_table(const DiagGeom &g, uint32_t *table, uint32_t *groups, uint32_t *tag, const PlanTag &want, hipStream_t st)
 {
-    hipLaunchKernelGGL(diag_groups_kernel, dim3(1), dim3(64), 0, st, g, groups);
+    hipLaunchKernelGGL(diag_groups_kernel, dim3(1), dim3(64), 0, st, g, groups, tag, want);
     const size_t nrec = (size_t)g.NBB * g.NG * g.K * g.NCS;
     const unsigned blocks = (unsigned)((nrec + 255) / 256 < 65535u * 8 ? (nrec + 255) / 256 : 65535u * 8);
-    hipLaunchKernelGGL(diag_table_kernel, dim3(blocks), dim3(256), 0, st, g, table);
+    hipLaunchKernelGGL(diag_table_kernel, dim3(blocks), dim3(256), 0, st, g, table, tag, want);
+    hipLaunchKernelGGL(stamp_tag_kernel, dim3(1), dim3(64), 0, st, tag, want);
     return (int)hipGetLastError();
 }
 
@@ -556,6 +593,7 @@ DiagWorkspace diag_carve(int op, const DiagGeom &g)
     DiagWorkspace w{};
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    take(kTagBytes);                                  // plan tag
     w.xp = take(diag_padded_floats(g) * 4);
     if (op == MFL_OP_MEANFIELD_FORWARD) w.xp2 = take(diag_padded_floats(g) * 4);
     w.ip4 = take(((size_t)g.B * g.plane + 64) * sizeof(F4));
@@ -593,8 +631,8 @@ int dispatch_diag(const DiagArgs &a, int mode, hipStream_t st)
 
 // Pads x (planes) and img, builds the address table and the weight-group list.  x_floats: the padded
 // buffer (front slack included) that receives x.
-int diag_prepare(const DiagGeom &g, const float *x, const float *img, float *x_floats, F4 *ip4, uint32_t *table,
-                 uint32_t *groups_dev, hipStream_t st)
+int diag_prepare(int op, void *workspace, const DiagGeom &g, const float *x, const float *img, float *x_floats, F4 *ip4,
+                 uint32_t *table, uint32_t *groups_dev, hipStream_t st)
 {
     const size_t n = (size_t)g.B * g.C * g.plane;
     MFL_CHECK_HIP(hipMemsetAsync(x_floats, 0, (size_t)g.FS * 4, st));
@@ -605,7 +643,7 @@ int diag_prepare(const DiagGeom &g, const float *x, const float *img, float *x_f
     hipLaunchKernelGGL(pad_image4_kernel, dim3(grid_for(ni)), dim3(kThreads), 0, st, img, ip4, g.B, g.H, g.W, g.Hp,
                        g.Wp, g.p0);
     MFL_CHECK_HIP(hipMemsetAsync(ip4 + ni, 0, 64 * sizeof(F4), st));
-    return launch_diag_table(g, table, groups_dev, st);
+    return launch_diag_table(g, table, groups_dev, (uint32_t *)workspace, make_tag(2, op, g.B, g.C, g.H, g.W, g.k), st);
 }
 
 void diag_lds(const DiagGeom &g, DiagArgs &a)
@@ -626,8 +664,9 @@ void diag_lds(const DiagGeom &g, DiagArgs &a)
 
 
 // ---- ring gather path (mfl_ring.hip): the forward operators for images at least 64 + k wide, odd k <= 11 ----
-__global__ void ring_table_kernel(RingGeom r, uint32_t *__restrict__ table)
+__global__ void ring_table_kernel(RingGeom r, uint32_t *__restrict__ table, const uint32_t *__restrict__ tag, PlanTag want)
 {
+    if (tag_matches(tag, want)) return;               // the workspace holds this plan already
     const DiagGeom &g = r.d;
     const size_t nrec = (size_t)g.NBB * g.NG * r.recs_per_wave * g.NCS;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrec; i += (size_t)gridDim.x * blockDim.x) {
@@ -651,6 +690,7 @@ RingWorkspace ring_carve(int op, const RingGeom &r)
     RingWorkspace w{};
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    take(kTagBytes);                                  // plan tag
     w.xp = take(diag_padded_floats(g) * 4);
     if (op == MFL_OP_MEANFIELD_FORWARD) w.xp2 = take(diag_padded_floats(g) * 4);
     w.ip4 = take(((size_t)g.B * g.plane + 64) * sizeof(F4));
@@ -690,8 +730,8 @@ int dispatch_ring(const RingArgs &a, int mode, hipStream_t st)
 }
 
 // Pads x (planes) and img and builds the record table.
-int ring_prepare(const RingGeom &r, const float *x, const float *img, const float *pos_w, const float *col_w, float *x_floats,
-                 F4 *ip4, uint32_t *table, float *wtab, hipStream_t st)
+int ring_prepare(int op, void *workspace, const RingGeom &r, const float *x, const float *img, const float *pos_w,
+                 const float *col_w, float *x_floats, F4 *ip4, uint32_t *table, float *wtab, hipStream_t st)
 {
     const DiagGeom &g = r.d;
     const size_t n = (size_t)g.B * g.C * g.plane;
@@ -705,7 +745,9 @@ int ring_prepare(const RingGeom &r, const float *x, const float *img, const floa
     MFL_CHECK_HIP(hipMemsetAsync(ip4 + ni, 0, 64 * sizeof(F4), st));
     const size_t nrec = (size_t)g.NBB * g.NG * r.recs_per_wave * g.NCS;
     const unsigned blocks = (unsigned)((nrec + 255) / 256 < 65535u * 8 ? (nrec + 255) / 256 : 65535u * 8);
-    hipLaunchKernelGGL(ring_table_kernel, dim3(blocks), dim3(256), 0, st, r, table);
+    const PlanTag want = make_tag(1, op, g.B, g.C, g.H, g.W, g.k);
+    hipLaunchKernelGGL(ring_table_kernel, dim3(blocks), dim3(256), 0, st, r, table, (const uint32_t *)workspace, want);
+    hipLaunchKernelGGL(stamp_tag_kernel, dim3(1), dim3(64), 0, st, (uint32_t *)workspace, want);
     RingArgs wa{};
     wa.r = r;
     wa.ip4 = ip4;
@@ -827,7 +869,7 @@ int mfl_local_forward(const float *x, const float *img, const float *cd, const f
         if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
         char *base = (char *)workspace;
         hipStream_t st = (hipStream_t)stream;
-        rc = ring_prepare(rg, x, img, pos_w, col_w, (float *)(base + ws.xp), (F4 *)(base + ws.ip4), (uint32_t *)(base + ws.table),
+        rc = ring_prepare(MFL_OP_LOCAL_FORWARD, workspace, rg, x, img, pos_w, col_w, (float *)(base + ws.xp), (F4 *)(base + ws.ip4), (uint32_t *)(base + ws.table),
                           (float *)(base + ws.wtab), st);
         if (rc) return rc;
         RingArgs ra{};
@@ -847,7 +889,7 @@ int mfl_local_forward(const float *x, const float *img, const float *cd, const f
         if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
         char *base = (char *)workspace;
         hipStream_t st = (hipStream_t)stream;
-        rc = diag_prepare(dg, x, img, (float *)(base + ws.xp), (F4 *)(base + ws.ip4), (uint32_t *)(base + ws.table),
+        rc = diag_prepare(MFL_OP_LOCAL_FORWARD, workspace, dg, x, img, (float *)(base + ws.xp), (F4 *)(base + ws.ip4), (uint32_t *)(base + ws.table),
                           (uint32_t *)(base + ws.groups), st);
         if (rc) return rc;
         DiagArgs da{};
@@ -875,7 +917,7 @@ int mfl_local_forward(const float *x, const float *img, const float *cd, const f
     F4 *ip4 = (F4 *)(base + ws.ip4);
     int *tab = (int *)(base + ws.tab);
     hipStream_t st = (hipStream_t)stream;
-    rc = launch_prepare(g, x, img, xp, ip4, tab, st);
+    rc = launch_prepare(workspace, g, x, img, xp, ip4, tab, st);
     if (rc) return rc;
     const GatherArgs ga{g, cd != nullptr, tab_lds, xp, ip4, cd, tab, pos_w, col_w};
     return dispatch_local_forward(cc, ga, y, st);
@@ -897,7 +939,7 @@ int mfl_local_backward(const float *x, const float *img, const float *cd, const 
         if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
         char *base = (char *)workspace;
         hipStream_t st = (hipStream_t)stream;
-        rc = diag_prepare(dg, x, img, (float *)(base + ws.xp), (F4 *)(base + ws.ip4), (uint32_t *)(base + ws.table),
+        rc = diag_prepare(MFL_OP_LOCAL_BACKWARD, workspace, dg, x, img, (float *)(base + ws.xp), (F4 *)(base + ws.ip4), (uint32_t *)(base + ws.table),
                           (uint32_t *)(base + ws.groups), st);
         if (rc) return rc;
         float *consts = (float *)(base + ws.consts), *P = (float *)(base + ws.psum), *Q = (float *)(base + ws.qsum);
@@ -948,7 +990,7 @@ int mfl_local_backward(const float *x, const float *img, const float *cd, const 
     float *dxp = (float *)(base + ws.dxp);
     float *partials = (float *)(base + ws.partials);
     hipStream_t st = (hipStream_t)stream;
-    rc = launch_prepare(g, x, img, xp, ip4, tab, st);
+    rc = launch_prepare(workspace, g, x, img, xp, ip4, tab, st);
     if (rc) return rc;
     MFL_CHECK_HIP(hipMemsetAsync(dxp, 0, padded_floats(g) * 4, st));
     const int nchunks = (g.C + cc - 1) / cc;
@@ -1001,7 +1043,7 @@ static int meanfield_forward_impl(const float *unary, const float *img, const fl
         char *base = (char *)workspace;
         hipStream_t st = (hipStream_t)stream;
         float *qa = (float *)(base + ws.xp), *qb = (float *)(base + ws.xp2);
-        rc = ring_prepare(rg, unary, img, pos_w, col_w, qa, (F4 *)(base + ws.ip4), (uint32_t *)(base + ws.table),
+        rc = ring_prepare(MFL_OP_MEANFIELD_FORWARD, workspace, rg, unary, img, pos_w, col_w, qa, (F4 *)(base + ws.ip4), (uint32_t *)(base + ws.table),
                           (float *)(base + ws.wtab), st);
         if (rc) return rc;
         MFL_CHECK_HIP(hipMemsetAsync(qb, 0, diag_padded_floats(g) * 4, st));   // borders of the other buffer
@@ -1041,7 +1083,7 @@ static int meanfield_forward_impl(const float *unary, const float *img, const fl
         char *base = (char *)workspace;
         hipStream_t st = (hipStream_t)stream;
         float *qa = (float *)(base + ws.xp), *qb = (float *)(base + ws.xp2);
-        rc = diag_prepare(dg, unary, img, qa, (F4 *)(base + ws.ip4), (uint32_t *)(base + ws.table),
+        rc = diag_prepare(MFL_OP_MEANFIELD_FORWARD, workspace, dg, unary, img, qa, (F4 *)(base + ws.ip4), (uint32_t *)(base + ws.table),
                           (uint32_t *)(base + ws.groups), st);
         if (rc) return rc;
         MFL_CHECK_HIP(hipMemsetAsync(qb, 0, diag_padded_floats(dg) * 4, st));   // borders of the other buffer
@@ -1089,7 +1131,7 @@ static int meanfield_forward_impl(const float *unary, const float *img, const fl
     int *tab = (int *)(base + ws.tab);
     float *msg = (float *)(base + ws.msg);
     hipStream_t st = (hipStream_t)stream;
-    rc = launch_prepare(g, unary, img, qa, ip4, tab, st);          // Q_0 = unary, padded
+    rc = launch_prepare(workspace, g, unary, img, qa, ip4, tab, st);          // Q_0 = unary, padded
     if (rc) return rc;
     MFL_CHECK_HIP(hipMemsetAsync(qb, 0, padded_floats(g) * 4, st)); // borders of the other buffer
     const size_t npix = (size_t)B * g.L;

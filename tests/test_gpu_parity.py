@@ -338,6 +338,50 @@ def test_backward_fixed_point_scale_follows_the_data(S, oracle):
         assert_close(host(dx), rdx, RTOL, f"dx, dy scaled by {f}")
 
 
+def test_plan_tag_reuse_and_invalidation(S, oracle):
+    """A workspace keeps its address tables between calls of the same operation and size (the table kernels find
+    their tag and return); a call of another operation on the same memory invalidates the plan.  Through the C
+    ABI on one caller-owned buffer: forward, forward again (plan reused), backward (other layout), forward."""
+    from semantic_segmentation_amd import _lib
+    lib, ptr = _lib.lib, _lib.ptr
+    shape = (1, 8, 70, 96, 5)
+    B, C, H, W, k = shape
+    x, img, dy = make_inputs(shape, 51)
+    X, I, DY = dev(x), dev(img), dev(dy)
+    pw, cw = scalar(0.3), scalar(-0.7)
+    n = max(int(lib.mfl_workspace_bytes(op, B, C, H, W, k, 1)) for op in (_lib.OP_LOCAL_FORWARD, _lib.OP_LOCAL_BACKWARD))
+    ws = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    ref = oracle.local_forward(x, 0.3, -0.7, k, img=img)
+    st = _lib.stream_of(X)
+
+    def forward():
+        y = torch.full_like(X, float("nan"))
+        assert lib.mfl_local_forward(ptr(X), ptr(I), None, ptr(pw), ptr(cw), ptr(y), B, C, H, W, k, ptr(ws), n, st) == 0
+        return host(y)
+
+    assert_close(forward(), ref, RTOL, "first call")
+    tag = ws[:32].clone()
+    assert tag.any()
+    assert_close(forward(), ref, RTOL, "second call, plan reused")
+    assert torch.equal(ws[:32], tag)
+    dx, dpar = torch.empty_like(X), torch.empty(2, device="cuda")
+    assert lib.mfl_local_backward(ptr(X), ptr(I), None, ptr(pw), ptr(cw), ptr(DY), ptr(dx), ptr(dpar), None, B, C, H, W, k,
+                                  ptr(ws), n, st) == 0
+    assert not torch.equal(ws[:32], tag)                       # another operation's plan now
+    rdx, _, _ = oracle.local_backward(x, 0.3, -0.7, k, dy, img=img)
+    assert_close(host(dx), rdx, RTOL, "backward on the shared buffer")
+    assert_close(forward(), ref, RTOL, "forward after the backward: plan rebuilt")
+    # the host side's kept workspaces
+    _lib.keep_plans(True)
+    try:
+        a = host(S.ops.local_forward(X, pw, cw, k, image=I))
+        b = host(S.ops.local_forward(X, pw, cw, k, image=I))
+        assert np.array_equal(a, b)
+        assert_close(a, ref, RTOL, "kept plan")
+    finally:
+        _lib.keep_plans(False)
+
+
 def test_iou_counts_and_reference_conventions(S):
     """Per-class counters on device against the reference's loop (AdvancedModel.py:469-483) restated with
     numpy: exact integers; IoU -1 for an absent class, class 0 skipped unless asked for, 255 = void."""
