@@ -46,7 +46,7 @@ using namespace mfl;
 #endif
 // ... and the plain window-sum kernels (modes 1, 2)
 #ifndef MFL_M12_WAVES
-#define MFL_M12_WAVES 2
+#define MFL_M12_WAVES 4
 #endif
 
 namespace {
@@ -234,11 +234,12 @@ struct Loop {
     template <int SA>
     __device__ __forceinline__ void classes(int col, float (&w)[KS])
     {
-        while (col < KS && (int)((cols_sa >> (4 * col)) & 15) == SA) {
-            for (int ky = 0; ky < KS; ++ky) tap<SA>(w);
-            ++col;
-        }
-        if constexpr (SA + 1 < KS) classes<SA + 1>(col, w);
+        // (one flat loop per class: with a loop over the columns around a loop over the rows the compiler kept a
+        // second copy of all accumulators across the inner loop, which doubled the kernel's register count)
+        int ncols = 0;
+        while (col + ncols < KS && (int)((cols_sa >> (4 * (col + ncols))) & 15) == SA) ++ncols;
+        for (int i = ncols * KS; i > 0; --i) tap<SA>(w);
+        if constexpr (SA + 1 < KS) classes<SA + 1>(col + ncols, w);
     }
 
     // Elements and weights of stream tap 0 requested, then the stream.
