@@ -77,3 +77,16 @@ def emu_diag():
         clang = "/opt/rocm/lib/llvm/bin/clang++"
         subprocess.check_call([clang, "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
     return ctypes.CDLL(so)
+
+
+@pytest.fixture(scope="session")
+def emu_ring():
+    """Host emulation of the stream gather kernels (records, thresholds, lane permute rule, ownership)."""
+    import ctypes
+    src = os.path.join(ROOT, "tests", "emu", "emu_ring.cpp")
+    so = os.path.join(ROOT, "tests", "emu", "libmfl_emu_ring.so")
+    hdrs = [os.path.join(ROOT, "semantic_segmentation_amd", "csrc", h) for h in ("mfl_core.h", "mfl_diag.h", "mfl_ring.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
+        clang = "/opt/rocm/lib/llvm/bin/clang++"
+        subprocess.check_call([clang, "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+    return ctypes.CDLL(so)
