@@ -110,13 +110,14 @@ def cpu_baseline(cfg, unary0, img0, crop=(512, 1024), repeats=5):
                       f"(total {sum(ts):.0f} s)"}
 
 
-def measured_traffic(key):
+def measured_traffic(key, pixels):
     """Memory-side bytes per launch of the fused step kernel from the committed PMC passes
-    (profiles/traffic.json says how they were collected and corrected); None when absent."""
+    (profiles/traffic.json says how they were collected and corrected), scaled from the pixels per launch of
+    that measurement to this rank's; None when absent."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)[key]
-        return int(t["traffic_bytes_per_launch"]), t["sources"]
+        return int(t["traffic_bytes_per_launch"] * (pixels / t["pixels_per_launch"])), t["sources"]
     except (OSError, KeyError, ValueError, TypeError):
         return None, None
 
@@ -236,7 +237,7 @@ def run_inference(job, key, steps, warmup, with_cpu):
     tflops = flops_per_launch / (launch_ms * 1e-3) / 1e12
     if job.rank != 0:
         return None
-    traffic, traffic_src = measured_traffic(key)
+    traffic, traffic_src = measured_traffic(key, pixels)
     res = {
         "value": round(iters * batch * H * W * steps / 1e6 / elapsed, 2),
         "ms_per_step": round(elapsed / steps * 1e3, 4),

@@ -49,6 +49,7 @@ for tag, pats in KERNELS.items():
         write = acc[step]["WRITE_SIZE"][0] / acc[step]["WRITE_SIZE"][1]
         traffic[tag] = {"kernel": step, "fetch_size_kb_per_launch": fetch, "write_size_kb_per_launch": write,
                         "fetch_correction": 2.0, "traffic_bytes_per_launch": int((2 * fetch + write) * 1024),
+                        "pixels_per_launch": {"c4": 16 * 1024 * 2048, "c2": 8 * 512 * 512}[tag],
                         "sources": [f"profiles/r02_pmc_{tag}.txt", "profiles/r02_pmc_fetch_calibration.txt"]}
 for path in glob.glob(os.path.join(SRC, "pmc_calib", "**", "*counter_collection.csv"), recursive=True):
     with open(os.path.join(DST, "r02_pmc_fetch_calibration.txt"), "w") as out:
