@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from conftest import ROOT
-from semantic_segmentation_amd.parallel import allreduce_gradients, shard_range
+from semantic_segmentation_amd.parallel import ShardedUpdate, allreduce_gradients, shard_range
 
 
 def test_shard_range_covers_batch():
@@ -58,6 +58,27 @@ def _worker(rank, world, port, tmp):
         assert abs(float(pw.grad) - dpw_full) <= 1e-5 * abs(dpw_full) + 1e-6
         assert abs(float(cw.grad) - dcw_full) <= 1e-5 * abs(dcw_full) + 1e-6
         assert frozen.grad is None and torch.equal(nograd.grad, torch.ones(2, 2))
+        # per-pixel affine parameters: reduce-scatter of the gradients, SGD on this rank's slice, all-gather of the
+        # parameters; must equal plain SGD on the summed gradients (sizes that do not divide by the world size)
+        torch.manual_seed(5)
+        wgt = torch.nn.Parameter(torch.randn(1, 3, 5, 7))
+        bias = torch.nn.Parameter(torch.randn(1, 3, 5, 7))
+        w0, b0_ = wgt.detach().clone(), bias.detach().clone()
+        gen = torch.Generator().manual_seed(100 + rank)
+        wgt.grad, bias.grad = torch.randn(wgt.shape, generator=gen), torch.randn(bias.shape, generator=gen)
+        total_w, total_b = torch.zeros_like(wgt), torch.zeros_like(bias)
+        for r in range(world):
+            gr = torch.Generator().manual_seed(100 + r)
+            total_w += torch.randn(wgt.shape, generator=gr)
+            total_b += torch.randn(bias.shape, generator=gr)
+        sharded = ShardedUpdate([wgt, bias])
+        assert sharded.shard.numel() == (2 * 105 + world - 1) // world
+        opt = torch.optim.SGD([sharded.shard], lr=0.1)
+        sharded.reduce_scatter_gradients()
+        opt.step()
+        sharded.all_gather_parameters()
+        assert torch.allclose(wgt.detach(), w0 - 0.1 * total_w, atol=1e-6)
+        assert torch.allclose(bias.detach(), b0_ - 0.1 * total_b, atol=1e-6)
         open(os.path.join(tmp, f"ok{rank}"), "w").close()
     finally:
         dist.destroy_process_group()
@@ -67,3 +88,16 @@ def test_two_rank_sharding_and_allreduce(tmp_path, oracle):
     port = 29500 + os.getpid() % 2000
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_sharded_update_with_one_rank_is_plain_sgd():
+    torch.manual_seed(3)
+    w = torch.nn.Parameter(torch.randn(2, 3, 4))
+    w0 = w.detach().clone()
+    w.grad = torch.ones_like(w)
+    sharded = ShardedUpdate([w])
+    opt = torch.optim.SGD([sharded.shard], lr=0.5)
+    sharded.reduce_scatter_gradients()
+    opt.step()
+    sharded.all_gather_parameters()
+    assert torch.allclose(w.detach(), w0 - 0.5)
