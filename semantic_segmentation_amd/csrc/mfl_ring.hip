@@ -274,72 +274,100 @@ __device__ __forceinline__ void stream_tap(const RingGeom &r, int i, int &ky, in
 
 // Weight table of a call: w[img][b-block][group][stream position][piece q][lane][4] with
 // w = pd*pos_w + col_w*|I(l) - I(l + tap)|^2 (LocalConvolution.py:84 with the colour distance of
-// AdvancedModel.py:547) for pixel n = 4q + j of the lane.  One wave per (image, b-block, group): per tap its
-// lanes compute the weights of the wave's 64 x k pixels in image order (slot sigma = lane + 64 i is pixel
-// sigma % k of lane sigma / k: consecutive lanes read consecutive pixels), pass them through LDS and
-// write them lane-major, 1 KiB per store instruction.
+// AdvancedModel.py:547) for pixel n = 4q + j of the lane.
+// One workgroup per (image, b-block, kWGroups consecutive groups).  A lane of the gather owns a diagonal whose
+// pixels are CK - 1 apart: loading along it touches one cache line per pixel.  Here the lanes of a wave walk
+// the a direction instead: at one b value the kWGroups * k pixels l = a + b*CK are CONSECUTIVE image pixels, one
+// per lane, so a load instruction covers 880 contiguous bytes (11 x 11, five groups); each wave takes a share of
+// the 64 + k - 1 b values that reach the block's 64 lanes.  Pixel (a, b) belongs to lane (b - BL*beta) + a % k of
+// group a / k: the weights go through LDS ([group][lane][n], two buffers, one barrier per tap) and leave
+// lane-major, 1 KiB per store instruction.
+constexpr int kWGroups = 5;
+
 template <int KS>
 __global__ void __launch_bounds__(256)
 weights_kernel(RingGeom rg, const F4 *__restrict__ ip4, const float *__restrict__ pos_w, const float *__restrict__ col_w,
                float *__restrict__ wtab)
 {
     constexpr int WQ = (KS + 3) / 4, WP = 4 * WQ + 1, K = KS * KS;
-    __shared__ float lds[4][2][64 * WP];
+    constexpr int ROWS = 64 + KS - 1;                   // b values that reach the 64 lanes of a b-block
+    constexpr int RPW = (ROWS + 3) / 4;                 // ... per wave
+    static_assert(kWGroups * KS <= 64, "one lane per pixel of the groups' a range");
+    __shared__ float lds[2][kWGroups][64 * WP];
     const DiagGeom &g = rg.d;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long unit = (long long)blockIdx.x * 4 + wave;          // (image, b-block, group)
-    const long long units = (long long)g.B * g.NBB * g.NG;
-    if (unit >= units) return;
-    const int gamma = (int)(unit % g.NG);
-    const int beta = (int)((unit / g.NG) % g.NBB);
-    const int img = (int)(unit / ((long long)g.NG * g.NBB));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ngq = (g.NG + kWGroups - 1) / kWGroups;
+    const int gq = blockIdx.x % ngq;
+    const int beta = (blockIdx.x / ngq) % g.NBB;
+    const int img = blockIdx.x / (ngq * g.NBB);
     const F4 *__restrict__ ip_b = ip4 + (size_t)img * g.plane;
     const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ip_b, 0, 0x7fffffff, 0x00020000);
     const float pw = *pos_w, cw = *col_w;
     const int ctr_off = g.p0 * g.Wp + g.p0;
-    int ioff[KS], place[KS];
-    float cr[KS], cg[KS], cb[KS];
+    // this lane's column: a = (first group)*k + lane, i.e. pixel n = lane % k of group gl = lane / k
+    const int gl = lane / KS, n = lane - gl * KS;
+    const long long a = (long long)gq * kWGroups * KS + lane;
+    const bool col_ok = lane < kWGroups * KS && a < g.CK;
+    int ioff[RPW], place[RPW];
+    float cr[RPW], cg[RPW], cb[RPW];
 #pragma unroll
-    for (int i = 0; i < KS; ++i) {
-        const int sigma = lane + 64 * i;
-        const int owner = sigma / KS, n = sigma - owner * KS;
-        const int aa = gamma * KS + n, bb = g.BL * beta + owner - n;
-        const long long l = (long long)aa + (long long)bb * g.CK;
-        const bool valid = owner < g.BL && bb >= 0 && l < g.L;
-        const int lc = valid ? (int)l : 0;
+    for (int j = 0; j < RPW; ++j) {
+        const int row = wave * RPW + j;
+        const long long bb = (long long)g.BL * beta + row - (KS - 1);
+        const long long l = a + bb * g.CK;
+        const int owner = row - (KS - 1) + n;
+        const bool ok = col_ok && row < ROWS && bb >= 0 && l < g.L && owner >= 0 && owner < g.BL;
+        const int lc = ok ? (int)l : 0;
         const int yy = lc / g.W, xx = lc - yy * g.W;
         const int ibase = yy * g.Wp + xx;
-        ioff[i] = ibase * 16;
-        place[i] = owner * WP + n;
+        ioff[j] = ibase * 16;
+        place[j] = ok ? owner * WP + n : -1;
         const F4 c = ip_b[ibase + ctr_off];
-        cr[i] = c.x; cg[i] = c.y; cb[i] = c.z;
+        cr[j] = c.x; cg[j] = c.y; cb[j] = c.z;
     }
-    float *out = wtab + (size_t)unit * K * (WQ * 256);
+    // zero both buffers once: places no thread writes (lanes that own no pixel, pixels past the image) stay 0
+    for (int i = tid; i < 2 * kWGroups * 64 * WP; i += 256) (&lds[0][0][0])[i] = 0.f;
+    __syncthreads();
+    const size_t unit0 = ((size_t)img * g.NBB + beta) * g.NG + (size_t)gq * kWGroups;
+    // the image loads of a tap are issued a tap ahead (behind the previous tap's table stores)
+    f3 nbv[RPW];
+    {
+        int ky, kx;
+        stream_tap(rg, 0, ky, kx);
+#pragma unroll
+        for (int j = 0; j < RPW; ++j)
+            nbv[j] = __builtin_bit_cast(f3, __builtin_amdgcn_raw_buffer_load_b96(irsrc, ioff[j], (ky * g.Wp + kx) * 16, 0));
+    }
     for (int pos = 0; pos < K; ++pos) {
         int ky, kx;
         stream_tap(rg, pos, ky, kx);
-        const int toff = ky * g.Wp + kx;
         const int dy = ky - g.p0, dx = kx - g.p0;
         const float pdw = (float)(dy * dy + dx * dx) * pw;
-        float *wt = lds[wave][pos & 1];
+        float *wt = lds[pos & 1][gl < kWGroups ? gl : 0];
+        int ky1, kx1;
+        stream_tap(rg, pos + 1 < K ? pos + 1 : pos, ky1, kx1);
+        const int toff1 = ky1 * g.Wp + kx1;
 #pragma unroll
-        for (int i = 0; i < KS; ++i) {
-            const f3 nb = __builtin_bit_cast(f3, __builtin_amdgcn_raw_buffer_load_b96(irsrc, ioff[i], toff * 16, 0));
-            const float d0 = cr[i] - nb.x, d1 = cg[i] - nb.y, d2 = cb[i] - nb.z;
+        for (int j = 0; j < RPW; ++j) {
+            const f3 nb = nbv[j];
+            nbv[j] = __builtin_bit_cast(f3, __builtin_amdgcn_raw_buffer_load_b96(irsrc, ioff[j], toff1 * 16, 0));
+            const float d0 = cr[j] - nb.x, d1 = cg[j] - nb.y, d2 = cb[j] - nb.z;
             const float cd = fmaf(d2, d2, fmaf(d1, d1, d0 * d0));
-            wt[place[i]] = fmaf(cd, cw, pdw);
+            if (place[j] >= 0) wt[place[j]] = fmaf(cd, cw, pdw);
         }
-        wave_sync();
-#pragma unroll
-        for (int q = 0; q < WQ; ++q) {
+        __syncthreads();
+        // (two buffers: the next tap writes the other one; the barrier of that tap separates this tap's reads
+        // from the writes of the tap after it)
+        for (int i = tid; i < kWGroups * WQ * 64; i += 256) {
+            const int ol = i & 63, q = (i >> 6) % WQ, gg = i / (64 * WQ);
+            if (gq * kWGroups + gg >= g.NG) continue;
+            const float *src = lds[pos & 1][gg] + ol * WP + 4 * q;
             f4 v;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = 4 * q + j < KS ? wt[lane * WP + 4 * q + j] : 0.f;
-            *reinterpret_cast<f4 *>(out + ((size_t)(pos * WQ + q) * 64 + lane) * 4) = v;
+            for (int jj = 0; jj < 4; ++jj) v[jj] = 4 * q + jj < KS ? src[jj] : 0.f;
+            float *out = wtab + (unit0 + gg) * (size_t)K * (WQ * 256);
+            *reinterpret_cast<f4 *>(out + ((size_t)(pos * WQ + q) * 64 + ol) * 4) = v;
         }
-        // (two buffers: the next tap writes the other one, the one after it meets this wave's reads of
-        // this tap long done; LDS operations of a wave complete in order)
     }
 }
 
@@ -666,9 +694,9 @@ int launch_cfg(const RingArgs &a, int mode, hipStream_t st)
     };
     if (mode == 3) {
         // the weight table of the call
-        const long long units = (long long)g.B * g.NBB * g.NG;
-        hipLaunchKernelGGL(weights_kernel<KS>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, a.r, a.ip4, a.pos_w, a.col_w,
-                           a.wtab_out);
+        const long long wgs = (long long)g.B * g.NBB * ((g.NG + kWGroups - 1) / kWGroups);
+        if (wgs >= (1LL << 31)) return MFL_ERR_TOO_LARGE;
+        hipLaunchKernelGGL(weights_kernel<KS>, dim3((unsigned)wgs), dim3(256), 0, st, a.r, a.ip4, a.pos_w, a.col_w, a.wtab_out);
         return (int)hipGetLastError();
     }
     int rc;
