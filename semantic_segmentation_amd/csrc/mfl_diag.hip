@@ -592,6 +592,8 @@ diag_kernel(DiagGeom g, int epi_rows, int tail_per_group, const float *__restric
     const int gi = wave % NGW, ci = wave / NGW;
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2); with the image index
     // fastest, image i of a batch of 8 stays on XCD i % 8.
+    // (image-major order with one eighth of an image's tiles per XCD, which pays for 1024 x 2048 images in the
+    // stream kernels, measured 5 % slower here: 8 x 22 MB of planes fit the memory-side cache either way)
     const int img = blockIdx.x % g.B;
     const int tile = blockIdx.x / g.B;
     const int gb = tile % g.NGB, beta = tile / g.NGB;
