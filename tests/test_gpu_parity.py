@@ -274,6 +274,22 @@ def test_150_labels_128x128_vs_oracle(mode, S, oracle):
         assert strict_rel_err_on_marginals(lq, ref) < RTOL
 
 
+@pytest.mark.parametrize("C", [33, 70, 100, 160])
+def test_label_step_channel_block_counts_vs_oracle(C, S, oracle):
+    """The fused label step is built for 2 .. 5 blocks of 32 output channels: one label count per build
+    (33: two blocks with one channel in the second; 160: all five full), affine + matrix, against the oracle."""
+    shape = (2, C, 20, 23, 3)          # 460 pixels per image: pixel tiles straddle the image boundary
+    unary, img, _ = make_inputs(shape, 61)
+    rng = np.random.default_rng(62)
+    compat = ((1 - np.eye(C)) + 0.01 * rng.standard_normal((C, C))).astype(np.float32) / 8
+    aw = (1 + 0.2 * rng.standard_normal((1, C, 20, 23))).astype(np.float32)
+    ab = (0.1 * rng.standard_normal((1, C, 20, 23))).astype(np.float32)
+    lq = host(S.ops.meanfield_forward(dev(unary), dev(img), scalar(-0.004), scalar(-0.003), 3, 2, dev(aw), dev(ab), dev(compat)))
+    ref = oracle.meanfield_forward(unary, img, -0.004, -0.003, 3, 2, aw, ab, compat)
+    assert_close(lq, ref, RTOL, "logq")
+    assert strict_rel_err_on_marginals(lq, ref) < RTOL
+
+
 def test_150_labels_full_size_properties(S):
     """150 labels, 512x512 (BASELINE config 5 image size), batch 2: marginals sum to one, and an image's result
     does not depend on what else is in the batch."""
