@@ -64,11 +64,16 @@ loop_pre_kernel(const float *__restrict__ g_in, int from_dq, const float *__rest
     float *sw = at + C * kPitch;           // [C][kPitch]  sum_b dA * M
     float *sb = sw + C * kPitch;           // [C][kPitch]  sum_b dA
     float *cacc = sb + C * kPitch;         // [C*C]        sum dP (x) A
+    float *cm = cacc + C * C;              // [C*C]        the label matrix (read once per workgroup)
     const int lane = threadIdx.x;
     const int l = blockIdx.x * kPix + lane;
     const bool ok = l < L;
     for (int c = 0; c < C; ++c) { sw[c * kPitch + lane] = 0.f; sb[c * kPitch + lane] = 0.f; }
-    for (int i = lane; i < C * C; i += kPix) cacc[i] = 0.f;
+    for (int i = lane; i < C * C; i += kPix) {
+        cacc[i] = 0.f;
+        cm[i] = compat ? compat[i] : 0.f;
+    }
+    __syncthreads();
     for (int b = 0; b < B; ++b) {
         const size_t base = (size_t)b * C * L + l;
         float sg = 0.f;
@@ -100,7 +105,7 @@ loop_pre_kernel(const float *__restrict__ g_in, int from_dq, const float *__rest
             float da;
             if (compat) {
                 da = 0.f;
-                for (int i = 0; i < C; ++i) da = fmaf(compat[i * C + j], dp[i * kPitch + lane], da);
+                for (int i = 0; i < C; ++i) da = fmaf(cm[i * C + j], dp[i * kPitch + lane], da);
             } else {
                 da = dp[j * kPitch + lane];
             }
@@ -137,22 +142,22 @@ loop_pre_kernel(const float *__restrict__ g_in, int from_dq, const float *__rest
         for (int i = lane; i < C * C; i += kPix) part[(size_t)blockIdx.x * C * C + i] = cacc[i];
 }
 
-// dcompat[i][j] (+)= sum over the workgroups' partials, in workgroup order.
-__global__ void loop_compat_reduce_kernel(const float *__restrict__ part, int nblk, int CC, float *__restrict__ dcompat, int first)
+// dcompat[i][j] (+)= sum over the workgroups' partials: one workgroup per matrix element, every thread sums a
+// fixed strided subset of the partials, then a fixed tree in LDS (the same order in every run).
+__global__ void __launch_bounds__(256)
+loop_compat_reduce_kernel(const float *__restrict__ part, int nblk, int CC, float *__restrict__ dcompat, int first)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= CC) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 3 < nblk; b += 4) {
-        s0 += part[(size_t)b * CC + idx];
-        s1 += part[(size_t)(b + 1) * CC + idx];
-        s2 += part[(size_t)(b + 2) * CC + idx];
-        s3 += part[(size_t)(b + 3) * CC + idx];
+    __shared__ float sh[256];
+    const int idx = blockIdx.x;
+    float s = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += 256) s += part[(size_t)b * CC + idx];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
     }
-    for (; b < nblk; ++b) s0 += part[(size_t)b * CC + idx];
-    const float s = (s0 + s1) + (s2 + s3);
-    dcompat[idx] = first ? s : dcompat[idx] + s;
+    if (threadIdx.x == 0) dcompat[idx] = first ? sh[0] : dcompat[idx] + sh[0];
 }
 
 // dU = dQ_0 + dls - softmax(U) * sum_c dls; one thread per pixel.  dparams = sum of the per-iteration pairs.
@@ -264,7 +269,7 @@ extern "C" int mfl_meanfield_backward(const float *unary, const float *img, cons
     int rc = mfl::meanfield_forward_keep(unary, img, pos_w, col_w, affine_w, affine_b, compat, logq_all, B, C, H, W, k, iters, sub,
                                          ws.sub_bytes, stream);
     if (rc) return rc;
-    const size_t lds = ((size_t)4 * C * kPitch + (size_t)C * C) * 4;
+    const size_t lds = ((size_t)4 * C * kPitch + (size_t)2 * C * C) * 4;
     const unsigned egrid = (unsigned)((n + 255) / 256 < 65535 * 8 ? (n + 255) / 256 : 65535 * 8);
     for (int t = iters - 1; t >= 0; --t) {
         const float *xt = unary;
@@ -279,7 +284,7 @@ extern "C" int mfl_meanfield_backward(const float *unary, const float *img, cons
                            logq_all + (size_t)t * n, m, affine_w, affine_b, compat, dm, dls, d_affine_w, d_affine_b,
                            compat ? part : nullptr, first, B, C, L);
         if (compat)
-            hipLaunchKernelGGL(loop_compat_reduce_kernel, dim3((C * C + 255) / 256), dim3(256), 0, st, part, ws.nblk, C * C,
+            hipLaunchKernelGGL(loop_compat_reduce_kernel, dim3(C * C), dim3(256), 0, st, part, ws.nblk, C * C,
                                d_compat, first);
         MFL_CHECK_HIP(hipGetLastError());
         rc = mfl_local_backward(xt, img, nullptr, pos_w, col_w, dm, dx, dpar + 2 * t, nullptr, B, C, H, W, k, sub, ws.sub_bytes,
