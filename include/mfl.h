@@ -143,11 +143,24 @@ int mfl_meanfield_forward(const float *unary, const float *img, const float *pos
                           mfl_stream_t stream);
 
 /*
+ * mfl_meanfield_forward that keeps every iterate: logq_iterates[t] = logQ_{t+1} for
+ * t = 0 .. iters-1, each [B][C][H][W] (the last one is what mfl_meanfield_forward
+ * returns).  For training: handing them to mfl_meanfield_backward saves it the
+ * recomputation of the forward loop.  Same workspace as MFL_OP_MEANFIELD_FORWARD.
+ */
+int mfl_meanfield_forward_iterates(const float *unary, const float *img, const float *pos_w, const float *col_w,
+                                   const float *affine_w, const float *affine_b, const float *compat, float *logq_iterates,
+                                   int B, int C, int H, int W, int k, int iters, void *workspace, size_t workspace_bytes,
+                                   mfl_stream_t stream);
+
+/*
  * Gradients of mfl_meanfield_forward for an incoming grad_logq = dL/dlogq: what
  * autograd derives when loss.backward() (AdvancedModel.py:299) runs through the
  * iterated composition AdvancedModel.py:222-244 (see mfl_meanfield_forward).
- * The forward loop is recomputed inside the call with every iterate kept in the
- * workspace (mfl_workspace_bytes(MFL_OP_MEANFIELD_BACKWARD, ...) grows with iters).
+ * logq_iterates: the [iters][B][C][H][W] output of mfl_meanfield_forward_iterates for
+ * the same inputs, or NULL: then the forward loop is recomputed inside the call with
+ * every iterate kept in the workspace (mfl_workspace_bytes(MFL_OP_MEANFIELD_BACKWARD,
+ * ...) grows with iters either way).
  *   grad_logq, d_unary: [B][C][H][W]
  *   dparams:    2 floats, overwritten with {d position_weight, d color_weight}
  *   d_affine_w, d_affine_b: [C][H][W], overwritten; non-NULL exactly when affine_w is
@@ -156,8 +169,9 @@ int mfl_meanfield_forward(const float *unary, const float *img, const float *pos
  * backward have a fixed order.
  */
 int mfl_meanfield_backward(const float *unary, const float *img, const float *pos_w, const float *col_w,
-                           const float *affine_w, const float *affine_b, const float *compat, const float *grad_logq,
-                           float *d_unary, float *dparams, float *d_affine_w, float *d_affine_b, float *d_compat,
+                           const float *affine_w, const float *affine_b, const float *compat, const float *logq_iterates,
+                           const float *grad_logq, float *d_unary, float *dparams, float *d_affine_w, float *d_affine_b,
+                           float *d_compat,
                            int B, int C, int H, int W, int k, int iters, void *workspace, size_t workspace_bytes,
                            mfl_stream_t stream);
 

@@ -32,7 +32,8 @@ SIGNATURES = {
     "mfl_local_backward": (_c_int, [_c_void] * 9 + [_c_int] * 5 + [_c_void, _c_size, _c_void]),
     "mfl_combine_forward": (_c_int, [_c_void, _c_void, _c_int, _c_void, _c_void] + [_c_int] * 4 + [_c_void]),
     "mfl_meanfield_forward": (_c_int, [_c_void] * 8 + [_c_int] * 6 + [_c_void, _c_size, _c_void]),
-    "mfl_meanfield_backward": (_c_int, [_c_void] * 13 + [_c_int] * 6 + [_c_void, _c_size, _c_void]),
+    "mfl_meanfield_forward_iterates": (_c_int, [_c_void] * 8 + [_c_int] * 6 + [_c_void, _c_size, _c_void]),
+    "mfl_meanfield_backward": (_c_int, [_c_void] * 14 + [_c_int] * 6 + [_c_void, _c_size, _c_void]),
     "mfl_meanfield_forward_noalloc": (_c_int, [_c_void] * 8 + [_c_int] * 6 + [_c_void]),
     "mfl_label_context_workspace_bytes": (_c_size, [_c_int] * 6),
     "mfl_label_context_forward": (_c_int, [_c_void] * 10 + [_c_int] * 6 + [_c_void, _c_size, _c_void]),

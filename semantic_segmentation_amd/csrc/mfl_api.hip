@@ -1183,6 +1183,16 @@ int mfl_meanfield_forward(const float *unary, const float *img, const float *pos
                                   workspace, workspace_bytes, stream);
 }
 
+int mfl_meanfield_forward_iterates(const float *unary, const float *img, const float *pos_w, const float *col_w,
+                                   const float *affine_w, const float *affine_b, const float *compat, float *logq_iterates,
+                                   int B, int C, int H, int W, int k, int iters, void *workspace, size_t workspace_bytes,
+                                   mfl_stream_t stream)
+{
+    if (!logq_iterates) return MFL_ERR_INVALID_ARGUMENT;
+    return meanfield_forward_impl(unary, img, pos_w, col_w, affine_w, affine_b, compat, nullptr, logq_iterates, B, C, H, W, k,
+                                  iters, workspace, workspace_bytes, stream);
+}
+
 int mfl_meanfield_forward_noalloc(const float *unary, const float *img, const float *pos_w, const float *col_w,
                                   const float *affine_w, const float *affine_b, const float *compat, float *logq,
                                   int B, int C, int H, int W, int k, int iters, mfl_stream_t stream)

@@ -241,7 +241,8 @@ size_t loop_backward_workspace_bytes(int B, int C, int H, int W, int k, int iter
 
 extern "C" int mfl_meanfield_backward(const float *unary, const float *img, const float *pos_w, const float *col_w,
                                       const float *affine_w, const float *affine_b, const float *compat,
-                                      const float *grad_logq, float *d_unary, float *dparams, float *d_affine_w,
+                                      const float *logq_iterates, const float *grad_logq, float *d_unary, float *dparams,
+                                      float *d_affine_w,
                                       float *d_affine_b, float *d_compat, int B, int C, int H, int W, int k, int iters,
                                       void *workspace, size_t workspace_bytes, mfl_stream_t stream)
 {
@@ -258,7 +259,8 @@ extern "C" int mfl_meanfield_backward(const float *unary, const float *img, cons
     if (!workspace || workspace_bytes < need) return MFL_ERR_WORKSPACE;
     const LoopWorkspace ws = loop_carve(B, C, H, W, k, iters);
     char *base = (char *)workspace;
-    float *logq_all = (float *)(base + ws.logq_all), *x = (float *)(base + ws.x), *m = (float *)(base + ws.m);
+    const float *logq_all = logq_iterates ? logq_iterates : (const float *)(base + ws.logq_all);
+    float *x = (float *)(base + ws.x), *m = (float *)(base + ws.m);
     float *dm = (float *)(base + ws.dm), *dx = (float *)(base + ws.dx), *dls = (float *)(base + ws.dls);
     float *dpar = (float *)(base + ws.dpar), *part = (float *)(base + ws.part);
     void *sub = base + ws.sub;
@@ -266,9 +268,13 @@ extern "C" int mfl_meanfield_backward(const float *unary, const float *img, cons
     const int L = H * W;
     const size_t n = (size_t)B * C * L;
 
-    int rc = mfl::meanfield_forward_keep(unary, img, pos_w, col_w, affine_w, affine_b, compat, logq_all, B, C, H, W, k, iters, sub,
-                                         ws.sub_bytes, stream);
-    if (rc) return rc;
+    int rc = 0;
+    if (!logq_iterates) {
+        // no iterates from the caller (mfl_meanfield_forward_iterates): the forward loop runs again and keeps them
+        rc = mfl::meanfield_forward_keep(unary, img, pos_w, col_w, affine_w, affine_b, compat, (float *)(base + ws.logq_all), B, C, H,
+                                         W, k, iters, sub, ws.sub_bytes, stream);
+        if (rc) return rc;
+    }
     const size_t lds = ((size_t)4 * C * kPitch + (size_t)2 * C * C) * 4;
     const unsigned egrid = (unsigned)((n + 255) / 256 < 65535 * 8 ? (n + 255) / 256 : 65535 * 8);
     for (int t = iters - 1; t >= 0; --t) {

@@ -46,17 +46,19 @@ class _MeanFieldFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, unary, image, pos_w, col_w, affine_w, affine_b, compat, k, iters):
         ctx.k, ctx.iters = k, iters
-        ctx.save_for_backward(unary, image, pos_w, col_w, affine_w, affine_b, compat)
-        return ops.meanfield_forward(unary, image, pos_w, col_w, k, iters, affine_w, affine_b, compat)
+        # every iterate is kept for the backward (iters tensors of the output's size) instead of recomputing the loop
+        iterates = ops.meanfield_forward_iterates(unary, image, pos_w, col_w, k, iters, affine_w, affine_b, compat)
+        ctx.save_for_backward(unary, image, pos_w, col_w, affine_w, affine_b, compat, iterates)
+        return iterates[iters - 1].clone()        # (the saved iterates stay private to the backward)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_logq):
-        unary, image, pos_w, col_w, affine_w, affine_b, compat = ctx.saved_tensors
+        unary, image, pos_w, col_w, affine_w, affine_b, compat, iterates = ctx.saved_tensors
         if ctx.needs_input_grad[1]:
             raise RuntimeError("MeanFieldLocal: no gradient for the image; detach it")
         d_unary, dparams, d_aw, d_ab, d_compat = ops.meanfield_backward(
-            unary, image, pos_w, col_w, ctx.k, ctx.iters, grad_logq, affine_w, affine_b, compat)
+            unary, image, pos_w, col_w, ctx.k, ctx.iters, grad_logq, affine_w, affine_b, compat, logq_iterates=iterates)
         need = ctx.needs_input_grad
         return (d_unary if need[0] else None, None, dparams[0:1] if need[2] else None, dparams[1:2] if need[3] else None,
                 d_aw.reshape(affine_w.shape) if (d_aw is not None and need[4]) else None,

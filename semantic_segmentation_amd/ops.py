@@ -97,12 +97,35 @@ def meanfield_forward(unary, image, pos_w, col_w, k, iters, affine_w=None, affin
 MEANFIELD_BACKWARD_MAX_LABELS = 32
 
 
-def meanfield_backward(unary, image, pos_w, col_w, k, iters, grad_logq, affine_w=None, affine_b=None, compat=None):
+def meanfield_forward_iterates(unary, image, pos_w, col_w, k, iters, affine_w=None, affine_b=None, compat=None):
+    """meanfield_forward that returns every iterate: [iters, B, C, H, W] log-marginals (the last one is the
+    result of meanfield_forward); meanfield_backward takes them instead of recomputing the loop."""
+    _lib.require_device(unary, image, pos_w, col_w, affine_w, affine_b, compat)
+    unary, image, affine_w, affine_b, compat = _c(unary), _c(image), _c(affine_w), _c(affine_b), _c(compat)
+    B, C, H, W = unary.shape
+    _check_appearance(B, H, W, k, image, None)
+    if (affine_w is None) != (affine_b is None):
+        raise ValueError("affine_w and affine_b must be given together")
+    if affine_w is not None and (affine_w.numel() != C * H * W or affine_b.numel() != C * H * W):
+        raise RuntimeError("affine parameters must hold C*H*W elements")
+    if compat is not None and compat.shape != (C, C):
+        raise RuntimeError(f"compat must be {(C, C)}, got {tuple(compat.shape)}")
+    out = torch.empty((iters,) + tuple(unary.shape), dtype=torch.float32, device=unary.device)
+    with torch.cuda.device(unary.device):
+        ws = _lib.workspace(_lib.OP_MEANFIELD_FORWARD, B, C, H, W, k, iters, unary.device)
+        _lib.check(lib.mfl_meanfield_forward_iterates(ptr(unary), ptr(image), ptr(pos_w), ptr(col_w), ptr(affine_w),
+                                                      ptr(affine_b), ptr(compat), ptr(out), B, C, H, W, k, iters, ptr(ws),
+                                                      ws.numel(), stream_of(unary)), "mfl_meanfield_forward_iterates")
+    return out
+
+
+def meanfield_backward(unary, image, pos_w, col_w, k, iters, grad_logq, affine_w=None, affine_b=None, compat=None,
+                       logq_iterates=None):
     """Gradients of meanfield_forward for grad_logq = dL/dlogq (autograd through AdvancedModel.py:222-244
     iterated; loss.backward(), AdvancedModel.py:299).  Returns (d_unary, dparams[2] = {d position_weight,
     d color_weight}, d_affine_w, d_affine_b, d_compat); the optional ones are None when the input is."""
-    _lib.require_device(unary, image, pos_w, col_w, grad_logq, affine_w, affine_b, compat)
-    unary, image, grad_logq = _c(unary), _c(image), _c(grad_logq)
+    _lib.require_device(unary, image, pos_w, col_w, grad_logq, affine_w, affine_b, compat, logq_iterates)
+    unary, image, grad_logq, logq_iterates = _c(unary), _c(image), _c(grad_logq), _c(logq_iterates)
     affine_w, affine_b, compat = _c(affine_w), _c(affine_b), _c(compat)
     B, C, H, W = unary.shape
     _check_appearance(B, H, W, k, image, None)
@@ -110,6 +133,8 @@ def meanfield_backward(unary, image, pos_w, col_w, k, iters, grad_logq, affine_w
         raise ValueError(f"meanfield_backward handles at most {MEANFIELD_BACKWARD_MAX_LABELS} labels, got {C}")
     if grad_logq.shape != unary.shape:
         raise RuntimeError(f"grad shape {tuple(grad_logq.shape)} does not match {tuple(unary.shape)}")
+    if logq_iterates is not None and logq_iterates.shape != (iters,) + tuple(unary.shape):
+        raise RuntimeError(f"logq_iterates must be {(iters,) + tuple(unary.shape)}, got {tuple(logq_iterates.shape)}")
     if (affine_w is None) != (affine_b is None):
         raise ValueError("affine_w and affine_b must be given together")
     if affine_w is not None and (affine_w.numel() != C * H * W or affine_b.numel() != C * H * W):
@@ -124,7 +149,8 @@ def meanfield_backward(unary, image, pos_w, col_w, k, iters, grad_logq, affine_w
     with torch.cuda.device(unary.device):
         ws = _lib.workspace(_lib.OP_MEANFIELD_BACKWARD, B, C, H, W, k, iters, unary.device)
         _lib.check(lib.mfl_meanfield_backward(ptr(unary), ptr(image), ptr(pos_w), ptr(col_w), ptr(affine_w), ptr(affine_b),
-                                              ptr(compat), ptr(grad_logq), ptr(d_unary), ptr(dparams), ptr(d_aw), ptr(d_ab),
+                                              ptr(compat), ptr(logq_iterates), ptr(grad_logq), ptr(d_unary), ptr(dparams),
+                                              ptr(d_aw), ptr(d_ab),
                                               ptr(d_compat), B, C, H, W, k, iters, ptr(ws), ws.numel(), stream_of(unary)),
                    "mfl_meanfield_backward")
     return d_unary, dparams, d_aw, d_ab, d_compat

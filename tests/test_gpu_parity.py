@@ -468,6 +468,16 @@ def test_meanfield_backward_vs_oracle(shape, iters, S, oracle):
     assert_close(host(dab).reshape(C, H, W), ref["dab"], RTOL, "d affine b")
     assert abs(float(dpar[0]) - ref["dpw"]) <= 2e-4 * abs(ref["dpw"]) + 1e-6
     assert abs(float(dpar[1]) - ref["dcw"]) <= 2e-4 * abs(ref["dcw"]) + 1e-6
+    # with the iterates of the forward handed over (no recomputation of the loop): the same gradients (to the last
+    # bits only where the local backward is the order-free one)
+    its = S.ops.meanfield_forward_iterates(dev(unary), dev(img), scalar(-0.004), scalar(-0.003), k, iters, dev(aw), dev(ab),
+                                           dev(compat))
+    plain = S.ops.meanfield_forward(dev(unary), dev(img), scalar(-0.004), scalar(-0.003), k, iters, dev(aw), dev(ab), dev(compat))
+    assert torch.equal(its[iters - 1], plain)
+    kept = S.ops.meanfield_backward(dev(unary), dev(img), scalar(-0.004), scalar(-0.003), k, iters, dev(G), dev(aw), dev(ab),
+                                    dev(compat), logq_iterates=its)
+    for a, b, name in zip(kept, (du, dpar, daw, dab, dcompat), ("dU", "dparams", "daw", "dab", "dcompat")):
+        assert_close(host(a), host(b), 1e-5, name + " with kept iterates")
     # the deterministic parts: everything but the local operator's scatter
     again = S.ops.meanfield_backward(dev(unary), dev(img), scalar(-0.004), scalar(-0.003), k, iters, dev(G), dev(aw), dev(ab),
                                      dev(compat))
