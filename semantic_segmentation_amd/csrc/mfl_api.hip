@@ -789,6 +789,15 @@ int scratch_pointer(void **out)
 }  // namespace
 
 namespace mfl {
+// The diagonal local backward in two phases sharing one workspace (the loop backward puts its own kernel between
+// them): sums = padding, tables and the two plain window sums P, Q (they do not depend on dy); apply = scatter of
+// dy * x, dx and the parameter gradients.
+bool local_backward_split_supported(int B, int C, int H, int W, int k);
+int local_backward_sums(const float *x, const float *img, int B, int C, int H, int W, int k, void *workspace, size_t workspace_bytes,
+                        mfl_stream_t stream, const float **P, const float **Q);
+int local_backward_apply(const float *x, const float *img, const float *pos_w, const float *col_w, const float *dy, float *dx,
+                         float *dparams, int B, int C, int H, int W, int k, void *workspace, size_t workspace_bytes,
+                         mfl_stream_t stream);
 size_t loop_backward_workspace_bytes(int B, int C, int H, int W, int k, int iters);   // mfl_loop_backward.hip
 bool label_step_supported(int C);                                                    // mfl_label_step.hip
 bool label_step_fits(int B, int C, int H, int W, int q_pad_k);
@@ -931,49 +940,13 @@ int mfl_local_backward(const float *x, const float *img, const float *cd, const 
     if (rc) return rc;
     if (!dx || !dparams || !pos_w || !col_w || (img == nullptr) == (cd == nullptr)) return MFL_ERR_INVALID_ARGUMENT;
     if (dcd && !cd) return MFL_ERR_INVALID_ARGUMENT;
-    DiagGeom dg;
-    if (img && diag_eligible(MFL_OP_LOCAL_BACKWARD, B, C, H, W, k, dg)) {
+    if (img && mfl::local_backward_split_supported(B, C, H, W, k)) {
         // dx = dy * S + scatter, S = pos_w * P + col_w * Q: two gathers with the weights (1, 0) and
         // (0, 1) give P and Q (and with them both parameter gradients), one scatter launch the rest
-        const DiagWorkspace ws = diag_carve(MFL_OP_LOCAL_BACKWARD, dg);
-        if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
-        char *base = (char *)workspace;
-        hipStream_t st = (hipStream_t)stream;
-        rc = diag_prepare(MFL_OP_LOCAL_BACKWARD, workspace, dg, x, img, (float *)(base + ws.xp), (F4 *)(base + ws.ip4), (uint32_t *)(base + ws.table),
-                          (uint32_t *)(base + ws.groups), st);
+        const float *P, *Q;
+        rc = mfl::local_backward_sums(x, img, B, C, H, W, k, workspace, workspace_bytes, stream, &P, &Q);
         if (rc) return rc;
-        float *consts = (float *)(base + ws.consts), *P = (float *)(base + ws.psum), *Q = (float *)(base + ws.qsum);
-        float *dxp = (float *)(base + ws.xp2), *partials = (float *)(base + ws.partials);   // (dxp: 64-bit elements)
-        const size_t n = (size_t)B * C * dg.L;
-        hipLaunchKernelGGL(diag_backward_consts_kernel, dim3(1), dim3(64), 0, st, consts);
-        hipLaunchKernelGGL(diag_backward_absmax_kernel, dim3(grid_for(n) < 1024 ? grid_for(n) : 1024), dim3(kThreads), 0, st, dy, x, n,
-                           img, (size_t)B * 3 * dg.L, consts);
-        hipLaunchKernelGGL(diag_backward_scale_kernel, dim3(1), dim3(64), 0, st, pos_w, col_w, k, consts);
-        MFL_CHECK_HIP(hipMemsetAsync(dxp, 0, diag_padded_floats(dg) * 8, st));
-        DiagArgs da{};
-        da.g = dg;
-        diag_lds(dg, da);
-        da.xp = (const float *)(base + ws.xp);
-        da.ip4 = (const F4 *)(base + ws.ip4);
-        da.table = (const uint32_t *)(base + ws.table);
-        da.groups = (const uint32_t *)(base + ws.groups);
-        da.pos_w = consts; da.col_w = consts + 1; da.y = P;
-        rc = dispatch_diag(da, 2, st);
-        if (rc) return rc;
-        da.pos_w = consts + 2; da.col_w = consts + 3; da.y = Q;
-        rc = dispatch_diag(da, 2, st);
-        if (rc) return rc;
-        da.pos_w = pos_w; da.col_w = col_w; da.y = nullptr;
-        da.unary = dy;
-        da.qp_out = dxp;
-        da.aw = consts + 4;                       // the scatter's fixed-point scale
-        rc = dispatch_diag(da, 3, st);
-        if (rc) return rc;
-        const int blocks = grid_for(n) < kDiagBackwardBlocks ? grid_for(n) : kDiagBackwardBlocks;
-        hipLaunchKernelGGL(diag_backward_finish_kernel, dim3(blocks), dim3(kThreads), 0, st, dy, x, P, Q, (const long long *)dxp + dg.FS, consts,
-                           pos_w, col_w, dx, partials, B * C, H, W, dg.Hp, dg.Wp, dg.p0);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kThreads), 0, st, partials, blocks, dparams);
-        return (int)hipGetLastError();
+        return mfl::local_backward_apply(x, img, pos_w, col_w, dy, dx, dparams, B, C, H, W, k, workspace, workspace_bytes, stream);
     }
     Geom g;
     int cc;
@@ -1235,6 +1208,82 @@ int mfl_iou_counts(const unsigned char *pred, const unsigned char *target, unsig
 }  // extern "C"
 
 namespace mfl {
+
+bool local_backward_split_supported(int B, int C, int H, int W, int k)
+{
+    DiagGeom dg;
+    return diag_eligible(MFL_OP_LOCAL_BACKWARD, B, C, H, W, k, dg);
+}
+
+int local_backward_sums(const float *x, const float *img, int B, int C, int H, int W, int k, void *workspace, size_t workspace_bytes,
+                        mfl_stream_t stream, const float **Pout, const float **Qout)
+{
+    DiagGeom dg;
+    if (!x || !img || !diag_eligible(MFL_OP_LOCAL_BACKWARD, B, C, H, W, k, dg)) return MFL_ERR_INVALID_ARGUMENT;
+    const DiagWorkspace ws = diag_carve(MFL_OP_LOCAL_BACKWARD, dg);
+    if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
+    char *base = (char *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = diag_prepare(MFL_OP_LOCAL_BACKWARD, workspace, dg, x, img, (float *)(base + ws.xp), (F4 *)(base + ws.ip4),
+                          (uint32_t *)(base + ws.table), (uint32_t *)(base + ws.groups), st);
+    if (rc) return rc;
+    float *consts = (float *)(base + ws.consts), *P = (float *)(base + ws.psum), *Q = (float *)(base + ws.qsum);
+    hipLaunchKernelGGL(diag_backward_consts_kernel, dim3(1), dim3(64), 0, st, consts);
+    DiagArgs da{};
+    da.g = dg;
+    diag_lds(dg, da);
+    da.xp = (const float *)(base + ws.xp);
+    da.ip4 = (const F4 *)(base + ws.ip4);
+    da.table = (const uint32_t *)(base + ws.table);
+    da.groups = (const uint32_t *)(base + ws.groups);
+    da.pos_w = consts; da.col_w = consts + 1; da.y = P;
+    rc = dispatch_diag(da, 2, st);
+    if (rc) return rc;
+    da.pos_w = consts + 2; da.col_w = consts + 3; da.y = Q;
+    rc = dispatch_diag(da, 2, st);
+    if (rc) return rc;
+    *Pout = P;
+    *Qout = Q;
+    return MFL_OK;
+}
+
+int local_backward_apply(const float *x, const float *img, const float *pos_w, const float *col_w, const float *dy, float *dx,
+                         float *dparams, int B, int C, int H, int W, int k, void *workspace, size_t workspace_bytes,
+                         mfl_stream_t stream)
+{
+    DiagGeom dg;
+    if (!x || !img || !dy || !dx || !dparams || !diag_eligible(MFL_OP_LOCAL_BACKWARD, B, C, H, W, k, dg))
+        return MFL_ERR_INVALID_ARGUMENT;
+    const DiagWorkspace ws = diag_carve(MFL_OP_LOCAL_BACKWARD, dg);
+    if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
+    char *base = (char *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    float *consts = (float *)(base + ws.consts), *P = (float *)(base + ws.psum), *Q = (float *)(base + ws.qsum);
+    float *dxp = (float *)(base + ws.xp2), *partials = (float *)(base + ws.partials);   // (dxp: 64-bit elements)
+    const size_t n = (size_t)B * C * dg.L;
+    hipLaunchKernelGGL(diag_backward_absmax_kernel, dim3(grid_for(n) < 1024 ? grid_for(n) : 1024), dim3(kThreads), 0, st, dy, x, n, img,
+                       (size_t)B * 3 * dg.L, consts);
+    hipLaunchKernelGGL(diag_backward_scale_kernel, dim3(1), dim3(64), 0, st, pos_w, col_w, k, consts);
+    MFL_CHECK_HIP(hipMemsetAsync(dxp, 0, diag_padded_floats(dg) * 8, st));
+    DiagArgs da{};
+    da.g = dg;
+    diag_lds(dg, da);
+    da.xp = (const float *)(base + ws.xp);
+    da.ip4 = (const F4 *)(base + ws.ip4);
+    da.table = (const uint32_t *)(base + ws.table);
+    da.groups = (const uint32_t *)(base + ws.groups);
+    da.pos_w = pos_w; da.col_w = col_w; da.y = nullptr;
+    da.unary = dy;
+    da.qp_out = dxp;
+    da.aw = consts + 4;                       // the scatter's fixed-point scale
+    const int rc = dispatch_diag(da, 3, st);
+    if (rc) return rc;
+    const int blocks = grid_for(n) < kDiagBackwardBlocks ? grid_for(n) : kDiagBackwardBlocks;
+    hipLaunchKernelGGL(diag_backward_finish_kernel, dim3(blocks), dim3(kThreads), 0, st, dy, x, P, Q, (const long long *)dxp + dg.FS, consts,
+                       pos_w, col_w, dx, partials, B * C, H, W, dg.Hp, dg.Wp, dg.p0);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kThreads), 0, st, partials, blocks, dparams);
+    return (int)hipGetLastError();
+}
 
 // The forward loop with logQ_{t+1} of every iteration kept (for the loop backward, mfl_loop_backward.hip).
 int meanfield_forward_keep(const float *unary, const float *img, const float *pos_w, const float *col_w, const float *affine_w,

@@ -47,14 +47,16 @@ __global__ void loop_exp_kernel(const float *__restrict__ logq, float *__restric
 // the sums over images (daw, dab) and over the pixels of the tile (dcompat) have a fixed order.
 //   g_in:    t = K-1: dL/dlogQ_K of the caller;  else dQ_{t+1} of the last local backward (from_dq)
 //   logq1:   logQ_{t+1}
-//   m:       M_t (local forward of Q_t)
+//   m:       M_t (local forward of Q_t), or NULL: then M_t = Q_t * (pos_w * P + col_w * Q) from the plain window
+//            sums P, Q of the local backward's first phase (xq = Q_t)
 //   dm:      out, gradient of M_t
 //   dls:     running sum of dz (first: overwritten)
 //   daw/dab: running sums (first: overwritten), [C][L]; NULL without the affine
 //   part:    out, this workgroup's C x C partial of dcompat (NULL without the matrix)
 __global__ void __launch_bounds__(kPix)
 loop_pre_kernel(const float *__restrict__ g_in, int from_dq, const float *__restrict__ logq1, const float *__restrict__ m,
-                const float *__restrict__ aw, const float *__restrict__ ab, const float *__restrict__ compat,
+                const float *__restrict__ xq, const float *__restrict__ psum, const float *__restrict__ qsum,
+                const float *__restrict__ pos_w, const float *__restrict__ col_w, const float *__restrict__ aw, const float *__restrict__ ab, const float *__restrict__ compat,
                 float *__restrict__ dm, float *__restrict__ dls, float *__restrict__ daw, float *__restrict__ dab,
                 float *__restrict__ part, int first, int B, int C, int L)
 {
@@ -68,6 +70,8 @@ loop_pre_kernel(const float *__restrict__ g_in, int from_dq, const float *__rest
     const int lane = threadIdx.x;
     const int l = blockIdx.x * kPix + lane;
     const bool ok = l < L;
+    const float pw = m ? 0.f : *pos_w, cw = m ? 0.f : *col_w;
+    auto message = [&](size_t o) { return m ? m[o] : xq[o] * fmaf(pw, psum[o], cw * qsum[o]); };
     for (int c = 0; c < C; ++c) { sw[c * kPitch + lane] = 0.f; sb[c * kPitch + lane] = 0.f; }
     for (int i = lane; i < C * C; i += kPix) {
         cacc[i] = 0.f;
@@ -83,7 +87,7 @@ loop_pre_kernel(const float *__restrict__ g_in, int from_dq, const float *__rest
                 q = __expf(logq1[base + (size_t)c * L]);
                 g = g_in[base + (size_t)c * L];
                 if (from_dq) g *= q;
-                const float mv = m[base + (size_t)c * L];
+                const float mv = message(base + (size_t)c * L);
                 a = aw ? fmaf(aw[(size_t)c * L + l], mv, ab[(size_t)c * L + l]) : mv;
             }
             dp[c * kPitch + lane] = g;      // g for now
@@ -112,7 +116,7 @@ loop_pre_kernel(const float *__restrict__ g_in, int from_dq, const float *__rest
             if (ok) {
                 float dmv = da;
                 if (aw) {
-                    const float mv = m[base + (size_t)j * L];
+                    const float mv = message(base + (size_t)j * L);
                     sw[j * kPitch + lane] = fmaf(da, mv, sw[j * kPitch + lane]);
                     sb[j * kPitch + lane] += da;
                     dmv = aw[(size_t)j * L + l] * da;
@@ -225,6 +229,14 @@ LoopWorkspace loop_carve(int B, int C, int H, int W, int k, int iters)
 
 namespace mfl {
 
+// (mfl_api.hip: the diagonal local backward in two phases)
+bool local_backward_split_supported(int B, int C, int H, int W, int k);
+int local_backward_sums(const float *x, const float *img, int B, int C, int H, int W, int k, void *workspace, size_t workspace_bytes,
+                        mfl_stream_t stream, const float **P, const float **Q);
+int local_backward_apply(const float *x, const float *img, const float *pos_w, const float *col_w, const float *dy, float *dx,
+                         float *dparams, int B, int C, int H, int W, int k, void *workspace, size_t workspace_bytes,
+                         mfl_stream_t stream);
+
 // (declared in mfl_api.hip: the forward loop that keeps every iterate)
 int meanfield_forward_keep(const float *unary, const float *img, const float *pos_w, const float *col_w, const float *affine_w,
                            const float *affine_b, const float *compat, float *logq_all, int B, int C, int H, int W, int k,
@@ -276,6 +288,7 @@ extern "C" int mfl_meanfield_backward(const float *unary, const float *img, cons
         if (rc) return rc;
     }
     const size_t lds = ((size_t)4 * C * kPitch + (size_t)2 * C * C) * 4;
+    const bool split = mfl::local_backward_split_supported(B, C, H, W, k);
     const unsigned egrid = (unsigned)((n + 255) / 256 < 65535 * 8 ? (n + 255) / 256 : 65535 * 8);
     for (int t = iters - 1; t >= 0; --t) {
         const float *xt = unary;
@@ -283,18 +296,28 @@ extern "C" int mfl_meanfield_backward(const float *unary, const float *img, cons
             hipLaunchKernelGGL(loop_exp_kernel, dim3(egrid), dim3(256), 0, st, logq_all + (size_t)(t - 1) * n, x, n);
             xt = x;
         }
-        rc = mfl_local_forward(xt, img, nullptr, pos_w, col_w, m, B, C, H, W, k, sub, ws.sub_bytes, stream);
+        // Where the diagonal kernels serve the local backward, its first phase (the plain window sums P, Q, which do
+        // not depend on the incoming gradient) also yields M_t = X_t * (pos_w * P + col_w * Q): no separate local forward.
+        const float *psum = nullptr, *qsum = nullptr;
+        if (split) {
+            rc = mfl::local_backward_sums(xt, img, B, C, H, W, k, sub, ws.sub_bytes, stream, &psum, &qsum);
+        } else {
+            rc = mfl_local_forward(xt, img, nullptr, pos_w, col_w, m, B, C, H, W, k, sub, ws.sub_bytes, stream);
+        }
         if (rc) return rc;
         const int first = t == iters - 1;
         hipLaunchKernelGGL(loop_pre_kernel, dim3(ws.nblk), dim3(kPix), lds, st, first ? grad_logq : dx, first ? 0 : 1,
-                           logq_all + (size_t)t * n, m, affine_w, affine_b, compat, dm, dls, d_affine_w, d_affine_b,
-                           compat ? part : nullptr, first, B, C, L);
+                           logq_all + (size_t)t * n, split ? nullptr : m, xt, psum, qsum, pos_w, col_w, affine_w, affine_b, compat, dm,
+                           dls, d_affine_w, d_affine_b, compat ? part : nullptr, first, B, C, L);
         if (compat)
-            hipLaunchKernelGGL(loop_compat_reduce_kernel, dim3(C * C), dim3(256), 0, st, part, ws.nblk, C * C,
-                               d_compat, first);
+            hipLaunchKernelGGL(loop_compat_reduce_kernel, dim3(C * C), dim3(256), 0, st, part, ws.nblk, C * C, d_compat, first);
         MFL_CHECK_HIP(hipGetLastError());
-        rc = mfl_local_backward(xt, img, nullptr, pos_w, col_w, dm, dx, dpar + 2 * t, nullptr, B, C, H, W, k, sub, ws.sub_bytes,
-                                stream);
+        if (split) {
+            rc = mfl::local_backward_apply(xt, img, pos_w, col_w, dm, dx, dpar + 2 * t, B, C, H, W, k, sub, ws.sub_bytes, stream);
+        } else {
+            rc = mfl_local_backward(xt, img, nullptr, pos_w, col_w, dm, dx, dpar + 2 * t, nullptr, B, C, H, W, k, sub, ws.sub_bytes,
+                                    stream);
+        }
         if (rc) return rc;
     }
     hipLaunchKernelGGL(loop_final_kernel, dim3((unsigned)(((size_t)B * L + 255) / 256)), dim3(256), 0, st, unary, dx, dls, d_unary,
