@@ -724,7 +724,7 @@ int dispatch_ring(const RingArgs &a, int mode, hipStream_t st)
 {
 #define MFL_RING_CASE(CHV, KSV) \
     if (a.r.d.CH == CHV && a.r.d.k == KSV) return launch_ring_ch##CHV##_k##KSV(a, mode, st);
-    MFL_RING_CASE(8, 9) MFL_RING_CASE(7, 11)
+    MFL_RING_CASE(8, 9) MFL_RING_CASE(7, 11) MFL_RING_CASE(10, 9) MFL_RING_CASE(10, 11)
 #undef MFL_RING_CASE
     return MFL_ERR_INVALID_ARGUMENT;
 }

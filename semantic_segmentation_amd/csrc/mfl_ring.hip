@@ -53,6 +53,7 @@ namespace {
 
 typedef float f3 __attribute__((ext_vector_type(3)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 typedef const uint32_t __attribute__((address_space(4))) *ConstWords;   // scalar loads: the table is never written here
 
 // Workgroups per image in the launch order: the tiles of an image padded to a multiple of 8 (one eighth per XCD).
@@ -94,12 +95,45 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, int voff, ui
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, (int)soff, 0));
 }
 
+// The k multiply-adds of a step run as packed pairs (v_pk_fma_f32: two pixels per instruction; the tap loop is
+// bound by instruction issue, one instruction per four cycles and SIMD with two waves resident).  A lane's k
+// accumulators of a channel and its k weights are therefore held as k / 2 register pairs plus one single
+// register, the shared elements (A, B) of a step as one pair.
+template <int KS>
+struct Weights {
+    f2 p[KS / 2];
+    float l;                                // pixel k - 1 (odd k)
+    __device__ __forceinline__ void set(int n, float v)
+    {
+        if (n < 2 * (KS / 2)) p[n / 2][n & 1] = v;
+        else l = v;
+    }
+    __device__ __forceinline__ float get(int n) const { return n < 2 * (KS / 2) ? p[n / 2][n & 1] : l; }
+};
+template <int CH, int KS>
+struct Accumulators {
+    f2 p[CH][KS / 2];
+    float l[CH];
+    __device__ __forceinline__ float get(int i, int n) const { return n < 2 * (KS / 2) ? p[i][n / 2][n & 1] : l[i]; }
+};
+
+// acc += w * e, per half: KIND 0 both pixels take e.x (side A), 1 both take e.y (side B), 2 the first takes
+// e.x and the second e.y.  In place by construction (a three-address form makes the compiler copy the
+// step's accumulators).
+template <int KIND>
+__device__ __forceinline__ void pk_fma(f2 &acc, f2 w, f2 e)
+{
+    if constexpr (KIND == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(w), "v"(e));
+    else if constexpr (KIND == 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(e));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(e));
+}
+
 template <int CH, int KS, int NGW, int NCS>
 struct Loop {
     using Cfg = RingCfg<CH, KS, NGW, NCS>;
     static constexpr int RECW = Cfg::RECW;
 
-    float (&acc)[CH][KS];
+    Accumulators<CH, KS> &acc;
     __amdgpu_buffer_rsrc_t rsrc;            // FS floats before the pad(x) planes of the image
     __amdgpu_buffer_rsrc_t wrsrc;           // this wave's part of the weight table: [position][piece][lane][4]
     ConstWords recp;                        // record of the current stream position
@@ -110,7 +144,7 @@ struct Loop {
     int pos;                                // stream position
     Offsets<CH> offn;                       // offsets of the next tap (refills)
     Thresholds<CH> thr;                     // thresholds of the current tap
-    float a[CH], b[CH];                     // shared elements of the current tap, refilled in place
+    f2 ab[CH];                              // shared elements (A, B) of the current tap, refilled in place
 #ifdef MFL_STAMPS
     // diagnostic build only: cycles per tap segment, summed over the taps
     unsigned long long seg[6], seg_t;
@@ -132,13 +166,18 @@ struct Loop {
 
     // One gather step: pixels n < KS - SA take side A, the others side B.
     template <int SA, int STEP>
-    __device__ __forceinline__ void step(const float (&w)[KS])
+    __device__ __forceinline__ void step(const Weights<KS> &w)
     {
-        constexpr int NA = KS - SA;
-        const float ea0 = a[STEP], eb0 = b[STEP];
+        constexpr int NA = KS - SA, KP = KS / 2;
+        const f2 e = ab[STEP];
 #ifndef MFL_ABL_NO_FMA
 #pragma unroll
-        for (int n = 0; n < KS; ++n) acc[STEP][n] = fmaf(w[n], n < NA ? ea0 : eb0, acc[STEP][n]);
+        for (int i = 0; i < KP; ++i) {
+            if (2 * i + 1 < NA) pk_fma<0>(acc.p[STEP][i], w.p[i], e);
+            else if (2 * i >= NA) pk_fma<1>(acc.p[STEP][i], w.p[i], e);
+            else pk_fma<2>(acc.p[STEP][i], w.p[i], e);
+        }
+        if constexpr (KS & 1) acc.l[STEP] = fmaf(w.l, KS - 1 < NA ? e.x : e.y, acc.l[STEP]);
 #endif
 #ifndef MFL_ABL_NO_CORR
         const uint32_t t16 = (thr.w[STEP / 2] >> (16 * (STEP & 1))) & 0xffffu;
@@ -147,40 +186,51 @@ struct Loop {
             // further where lane - T >= n (mfl_diag.h, diag_side).  The FMAs above took the shared element for
             // every pixel; this adds w[n] * (extra - shared) where it applies.  The extra element of a lane
             // is the shared element of lane + gap: a lane permute (the lanes that own pixels end gap lanes
-            // before the wave does).  The updates are in-place instructions by construction: a three-address
-            // FMA here makes the compiler copy the step's accumulators on the common path.
+            // before the wave does).
+            // (scalar copies first: __builtin_bit_cast applied to a vector element reads element 0 whichever is named)
+            const float ea0 = e.x, eb0 = e.y;
             const float xa = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsrc, __builtin_bit_cast(int, ea0)));
             const float xb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsrc, __builtin_bit_cast(int, eb0)));
-            const float da = xa - ea0, db = xb - eb0;
+            f2 d;
+            d.x = xa - e.x;
+            d.y = xb - e.y;
             const int pA = lane - ((int)(t16 & 255u) - 64), pB = lane - ((int)(t16 >> 8) - 64);
 #pragma unroll
-            for (int n = 0; n < KS; ++n) {
-                const float t = (n < NA ? pA : pB) >= n ? w[n] : 0.f;
-                asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[STEP][n]) : "v"(t), "v"(n < NA ? da : db));
+            for (int i = 0; i < KP; ++i) {
+                f2 t;
+                t.x = (2 * i < NA ? pA : pB) >= 2 * i ? w.p[i].x : 0.f;
+                t.y = (2 * i + 1 < NA ? pA : pB) >= 2 * i + 1 ? w.p[i].y : 0.f;
+                if (2 * i + 1 < NA) pk_fma<0>(acc.p[STEP][i], t, d);
+                else if (2 * i >= NA) pk_fma<1>(acc.p[STEP][i], t, d);
+                else pk_fma<2>(acc.p[STEP][i], t, d);
+            }
+            if constexpr (KS & 1) {
+                const float t = (KS - 1 < NA ? pA : pB) >= KS - 1 ? w.l : 0.f;
+                asm("v_fmac_f32 %0, %1, %2" : "+v"(acc.l[STEP]) : "v"(t), "v"(KS - 1 < NA ? d.x : d.y));
             }
         }
 #endif
     }
 
     template <int SA, int STEP>
-    __device__ __forceinline__ void steps(const float (&w)[KS])
+    __device__ __forceinline__ void steps(const Weights<KS> &w)
     {
         step<SA, STEP>(w);
 #ifndef MFL_ABL_NO_GLOADS
         // the next tap's elements into the registers this step has just consumed
-        a[STEP] = buf_load(rsrc, lane * 4, offn.a[STEP]);
-        b[STEP] = buf_load(rsrc, lane * 4, offn.b[STEP]);
+        ab[STEP].x = buf_load(rsrc, lane * 4, offn.a[STEP]);
+        ab[STEP].y = buf_load(rsrc, lane * 4, offn.b[STEP]);
 #endif
         if constexpr (STEP + 1 < CH) steps<SA, STEP + 1>(w);
     }
 
     // The k weights of the lane's pixels at stream position i (positions past the end repeat the last one).
-    __device__ __forceinline__ void load_weights(float (&w)[KS], int i) const
+    __device__ __forceinline__ void load_weights(Weights<KS> &w, int i) const
     {
         constexpr int K = KS * KS;
         const int ic = i < K ? i : K - 1;
 #ifdef MFL_ABL_NO_WLOADS
-        for (int n = 0; n < KS; ++n) w[n] = (float)(ic + n);
+        for (int n = 0; n < KS; ++n) w.set(n, (float)(ic + n));
         return;
 #endif
 #pragma unroll
@@ -188,19 +238,19 @@ struct Loop {
             const f4 v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16, (ic * Cfg::WQ + q) * 1024, MFL_NT_W));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (4 * q + j < KS) w[4 * q + j] = v[j];
+                if (4 * q + j < KS) w.set(4 * q + j, v[j]);
         }
     }
 
     // One tap of alignment class SA at stream position `pos` with the weights `w` (loaded a tap ago).
     template <int SA>
-    __device__ __forceinline__ void tap(float (&w)[KS])
+    __device__ __forceinline__ void tap(Weights<KS> &w)
     {
         MFL_SEG(5);
         // requested now, used from the end of this tap on: the weights and thresholds of the next tap, the
         // element offsets of the tap after it (the stream's last record repeats itself)
         constexpr int K = KS * KS;
-        float wn[KS];
+        Weights<KS> wn;
         load_weights(wn, pos + 1);
 #ifdef MFL_ABL_NO_RECORDS
         ConstWords rec1 = recp;
@@ -222,8 +272,7 @@ struct Loop {
         recp = rec1;
         thr = thr1;
         offn = off2;
-#pragma unroll
-        for (int n = 0; n < KS; ++n) w[n] = wn[n];
+        w = wn;
         MFL_SEG(2);
         ++pos;
     }
@@ -232,7 +281,7 @@ struct Loop {
     // updated in place through one chain of loops, no two bodies meet in a common successor), then the
     // next class.
     template <int SA>
-    __device__ __forceinline__ void classes(int col, float (&w)[KS])
+    __device__ __forceinline__ void classes(int col, Weights<KS> &w)
     {
         // (one flat loop per class: with a loop over the columns around a loop over the rows the compiler kept a
         // second copy of all accumulators across the inner loop, which doubled the kernel's register count)
@@ -249,12 +298,12 @@ struct Loop {
         load_offsets(recp);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            a[c] = buf_load(rsrc, lane * 4, offn.a[c]);
-            b[c] = buf_load(rsrc, lane * 4, offn.b[c]);
+            ab[c].x = buf_load(rsrc, lane * 4, offn.a[c]);
+            ab[c].y = buf_load(rsrc, lane * 4, offn.b[c]);
         }
         load_thresholds(recp);
         load_offsets(recp + rec_stride);
-        float w[KS];
+        Weights<KS> w;
         load_weights(w, 0);
 #ifdef MFL_STAMPS
         for (int i = 0; i < 6; ++i) seg[i] = 0;
@@ -373,7 +422,7 @@ weights_kernel(RingGeom rg, const F4 *__restrict__ ip4, const float *__restrict_
 
 // MODE 0: fused mean-field update   MODE 1: y = x * window sums   MODE 2: y = window sums
 template <int CH, int KS, int NGW, int NCS, int MODE>
-__global__ void __launch_bounds__(64 * NGW * NCS) __attribute__((amdgpu_waves_per_eu(MODE == 0 ? MFL_M0_WAVES : MFL_M12_WAVES)))
+__global__ void __launch_bounds__(64 * NGW * NCS) __attribute__((amdgpu_waves_per_eu(MODE == 0 || CH >= 10 ? MFL_M0_WAVES : MFL_M12_WAVES)))
 ring_kernel(RingGeom rg, int lds_floats, int tail_per_group, const float *__restrict__ xp, const F4 *__restrict__ ip4,
             const uint32_t *__restrict__ table, const float *__restrict__ wtab, const float *__restrict__ pos_w, const float *__restrict__ col_w,
             const float *__restrict__ unary, const float *__restrict__ aw, const float *__restrict__ ab,
@@ -413,11 +462,13 @@ ring_kernel(RingGeom rg, int lds_floats, int tail_per_group, const float *__rest
     const size_t img_off = (size_t)img * C * g.plane;
     const float *in_b = xp + img_off;                 // FS floats before the image's padded planes
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in_b, 0, 0x7fffffff, 0x00020000);
-    float acc[CH][KS];
+    Accumulators<CH, KS> acc;
 #pragma unroll
-    for (int i = 0; i < CH; ++i)
+    for (int i = 0; i < CH; ++i) {
 #pragma unroll
-        for (int n = 0; n < KS; ++n) acc[i][n] = 0.f;
+        for (int n = 0; n < KS / 2; ++n) acc.p[i][n] = f2{0.f, 0.f};
+        acc.l[i] = 0.f;
+    }
 
     const int gamma_t = live ? gamma : g.NG - 1;      // a wave without a group works on the last group (results dropped)
     const size_t wunit = ((size_t)img * g.NBB + beta) * g.NG + gamma_t;
@@ -425,7 +476,7 @@ ring_kernel(RingGeom rg, int lds_floats, int tail_per_group, const float *__rest
         (void *)(wtab + wunit * (size_t)(KS * KS) * (Cfg::WQ * 256)), 0, 0x7fffffff, 0x00020000);
     Loop<CH, KS, NGW, NCS> loop{acc, rsrc, wrsrc,
                                 (ConstWords)(uintptr_t)(table + ring_record_index(rg, beta, gamma_t, 0, ci)),
-                                g.NCS * g.RECW, rg.cols_kx, rg.cols_sa, g.gap, lane, ((lane + g.gap) & 63) * 4, 0, {}, {}, {}, {}};
+                                g.NCS * g.RECW, rg.cols_kx, rg.cols_sa, g.gap, lane, ((lane + g.gap) & 63) * 4, 0, {}, {}, {}};
 #ifdef MFL_STAMPS
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
@@ -467,7 +518,7 @@ ring_kernel(RingGeom rg, int lds_floats, int tail_per_group, const float *__rest
                 if (br >= 0 && br < CBR) {
                     float *dst = lds + (ci * CH * CBR + br) * Cfg::RUNP + gi * KS + n;
 #pragma unroll
-                    for (int i = 0; i < CH; ++i) dst[i * cstride] = acc[i][n];
+                    for (int i = 0; i < CH; ++i) dst[i * cstride] = acc.get(i, n);
                 }
             }
         }
@@ -660,6 +711,9 @@ size_t lds_bytes_cfg(const RingGeom &r)
     if (epi > need) need = epi;
     const size_t tail = ((size_t)g.CK + (size_t)Cfg::NW * kTailPix * (g.K + 2 * g.C)) * 4;
     if (g.tail_lanes && tail > need) need = tail;
+#ifdef MFL_EXP_LDS_MIN
+    if (need < (size_t)MFL_EXP_LDS_MIN) need = MFL_EXP_LDS_MIN;    // timing experiment: fewer workgroups per CU
+#endif
     return (need + 255) & ~(size_t)255;
 }
 

@@ -27,6 +27,8 @@ struct RingArgs {
 #define MFL_DECLARE_RING(CHV, KSV) int launch_ring_ch##CHV##_k##KSV(const RingArgs &a, int mode, hipStream_t st);
 MFL_DECLARE_RING(8, 9)
 MFL_DECLARE_RING(7, 11)
+MFL_DECLARE_RING(10, 9)
+MFL_DECLARE_RING(10, 11)
 
 }  // namespace mfl
 

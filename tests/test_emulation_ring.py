@@ -44,9 +44,12 @@ def test_ring_geometry_and_eligibility(emu_ring):
     # BASELINE config 4: 19 labels, 1024x2048, 11x11
     assert emu_ring.emu_ring_geom(16, 19, 1024, 2048, 11, out) == 0
     nbb, ng, ngw, ncs, ch, bl, tail, recw = list(out)
-    assert (ng, ngw, ncs, ch, bl) == (19 * 11, 2, 3, 7, 54)
+    assert (ng, ngw, ncs, ch, bl) == (19 * 11, 2, 2, 10, 54)        # two waves of 10 channels instead of three of 7
     assert nbb * bl + tail >= (1024 * 2048 + 19 * 121 - 1) // (19 * 121) + 10      # all b values plus the k - 1 shifted ones
     assert recw % 4 == 0 and recw >= 2 * ch + (ch + 1) // 2
+    # 21 labels: the wide slices would not save a wave per group, so 3 x 7 stays
+    assert emu_ring.emu_ring_geom(8, 21, 512, 512, 11, out) == 0
+    assert tuple(out)[2:5] == (2, 3, 7)
     # windows the stream kernels are not built for, narrow images, too many labels
     assert emu_ring.emu_ring_supported(21, 512, 512, 7) == 0
     assert emu_ring.emu_ring_supported(19, 1024, 70, 11) == 0
