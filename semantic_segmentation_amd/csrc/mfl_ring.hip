@@ -324,28 +324,45 @@ __device__ __forceinline__ void stream_tap(const RingGeom &r, int i, int &ky, in
 // Weight table of a call: w[img][b-block][group][stream position][piece q][lane][4] with
 // w = pd*pos_w + col_w*|I(l) - I(l + tap)|^2 (LocalConvolution.py:84 with the colour distance of
 // AdvancedModel.py:547) for pixel n = 4q + j of the lane.
-// One workgroup per (image, b-block, kWGroups consecutive groups).  A lane of the gather owns a diagonal whose
-// pixels are CK - 1 apart: loading along it touches one cache line per pixel.  Here the lanes of a wave walk
-// the a direction instead: at one b value the kWGroups * k pixels l = a + b*CK are CONSECUTIVE image pixels, one
-// per lane, so a load instruction covers 880 contiguous bytes (11 x 11, five groups); each wave takes a share of
-// the 64 + k - 1 b values that reach the block's 64 lanes.  Pixel (a, b) belongs to lane (b - BL*beta) + a % k of
-// group a / k: the weights go through LDS ([group][lane][n], two buffers, one barrier per tap) and leave
-// lane-major, 1 KiB per store instruction.
-constexpr int kWGroups = 5;
+// One workgroup (eight waves) per (image, b-block, WG consecutive groups).  A lane of the gather owns a diagonal
+// whose pixels are CK - 1 apart: loading along it touches one cache line per pixel.  Here the lanes of a wave
+// walk the a direction instead: at one b value the WG * k pixels l = a + b*CK are CONSECUTIVE image pixels, one
+// per lane, and the k - 1 lanes after them load the pixels to their right.  For one window row ky a lane loads
+// ONE image pixel (row y + ky of its column); the k neighbours of that window row are the pixels of the next
+// k lanes, reached by shifting the registers one lane per tap (v_mov_b32_dpp wave_shl:1): k loads per pixel
+// instead of k * k.  A run that crosses the end of an image row (x0 + WG*k > W) takes the plain path, one
+// load per lane and tap.  Each wave takes a share of the 64 + k - 1 b values that reach the block's 64 lanes.
+// Pixel (a, b) belongs to lane (b - BL*beta) + a % k of group a / k: the weights go through LDS
+// ([group][lane][n], two buffers, one barrier per tap) and leave lane-major, 1 KiB per store instruction.
+template <int KS>
+struct WeightsCfg {
+    static constexpr int WG = (64 - (KS - 1)) / KS;        // groups per workgroup
+    static constexpr int NPX = WG * KS;                     // their pixels along a
+    static constexpr int NWV = 8;                           // waves per workgroup
+};
+
+__device__ __forceinline__ float shift_left_lane(float v)
+{
+    // lane i takes the value of lane i + 1 (the last lane takes 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
 
 template <int KS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * WeightsCfg<KS>::NWV) __attribute__((amdgpu_waves_per_eu(4, 4)))
 weights_kernel(RingGeom rg, const F4 *__restrict__ ip4, const float *__restrict__ pos_w, const float *__restrict__ col_w,
                float *__restrict__ wtab)
 {
+    using WC = WeightsCfg<KS>;
+    constexpr int WG = WC::WG, NPX = WC::NPX, NWV = WC::NWV, NT = 64 * NWV;
     constexpr int WQ = (KS + 3) / 4, WP = 4 * WQ + 1, K = KS * KS;
+    constexpr int GST = 64 * WP + 17;                   // floats per group in LDS (the groups start on different banks)
     constexpr int ROWS = 64 + KS - 1;                   // b values that reach the 64 lanes of a b-block
-    constexpr int RPW = (ROWS + 3) / 4;                 // ... per wave
-    static_assert(kWGroups * KS <= 64, "one lane per pixel of the groups' a range");
-    __shared__ float lds[2][kWGroups][64 * WP];
+    constexpr int RPW = (ROWS + NWV - 1) / NWV;         // ... per wave
+    __shared__ float lds[2][WG * GST];
     const DiagGeom &g = rg.d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ngq = (g.NG + kWGroups - 1) / kWGroups;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ngq = (g.NG + WG - 1) / WG;
     const int gq = blockIdx.x % ngq;
     const int beta = (blockIdx.x / ngq) % g.NBB;
     const int img = blockIdx.x / (ngq * g.NBB);
@@ -355,67 +372,80 @@ weights_kernel(RingGeom rg, const F4 *__restrict__ ip4, const float *__restrict_
     const int ctr_off = g.p0 * g.Wp + g.p0;
     // this lane's column: a = (first group)*k + lane, i.e. pixel n = lane % k of group gl = lane / k
     const int gl = lane / KS, n = lane - gl * KS;
-    const long long a = (long long)gq * kWGroups * KS + lane;
-    const bool col_ok = lane < kWGroups * KS && a < g.CK;
+    const long long a0 = (long long)gq * NPX;
+    const bool col_ok = lane < NPX && a0 + lane < g.CK;
     int ioff[RPW], place[RPW];
+    int rowoff[RPW];                                    // wave-uniform: the window origin of lane 0's pixel, in bytes
+    uint32_t plain = 0;                                 // bit j: row j crosses the end of an image row (or is empty)
     float cr[RPW], cg[RPW], cb[RPW];
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
         const int row = wave * RPW + j;
         const long long bb = (long long)g.BL * beta + row - (KS - 1);
-        const long long l = a + bb * g.CK;
+        const long long l0 = a0 + bb * g.CK;            // pixel of lane 0
+        const long long l = l0 + lane;
         const int owner = row - (KS - 1) + n;
         const bool ok = col_ok && row < ROWS && bb >= 0 && l < g.L && owner >= 0 && owner < g.BL;
         const int lc = ok ? (int)l : 0;
         const int yy = lc / g.W, xx = lc - yy * g.W;
         const int ibase = yy * g.Wp + xx;
         ioff[j] = ibase * 16;
-        place[j] = ok ? owner * WP + n : -1;
+        place[j] = ok ? gl * GST + owner * WP + n : -1;
         const F4 c = ip_b[ibase + ctr_off];
         cr[j] = c.x; cg[j] = c.y; cb[j] = c.z;
+        const bool row_ok = row < ROWS && bb >= 0 && l0 < g.L;
+        const int l0c = row_ok ? (int)l0 : 0;
+        const int y0 = l0c / g.W, x0 = l0c - y0 * g.W;
+        rowoff[j] = (y0 * g.Wp + x0) * 16;
+        if (!row_ok || x0 + NPX > g.W) plain |= 1u << j;
     }
+    // stream position of tap column kx, 4 bits each
+    unsigned long long colpos = 0;
+    for (int col = 0; col < KS; ++col) colpos |= (unsigned long long)col << (4 * (int)((rg.cols_kx >> (4 * col)) & 15));
     // zero both buffers once: places no thread writes (lanes that own no pixel, pixels past the image) stay 0
-    for (int i = tid; i < 2 * kWGroups * 64 * WP; i += 256) (&lds[0][0][0])[i] = 0.f;
+    for (int i = tid; i < 2 * WG * GST; i += NT) (&lds[0][0])[i] = 0.f;
     __syncthreads();
-    const size_t unit0 = ((size_t)img * g.NBB + beta) * g.NG + (size_t)gq * kWGroups;
-    // the image loads of a tap are issued a tap ahead (behind the previous tap's table stores)
-    f3 nbv[RPW];
-    {
-        int ky, kx;
-        stream_tap(rg, 0, ky, kx);
+    const size_t unit0 = ((size_t)img * g.NBB + beta) * g.NG + (size_t)gq * WG;
+    for (int ky = 0; ky < KS; ++ky) {
+        // (no request ahead: with two workgroups per CU the other one works while these arrive, and the registers a
+        // second set of pixels would take are what keeps the second workgroup off the CU)
+        f3 cur[RPW];
 #pragma unroll
         for (int j = 0; j < RPW; ++j)
-            nbv[j] = __builtin_bit_cast(f3, __builtin_amdgcn_raw_buffer_load_b96(irsrc, ioff[j], (ky * g.Wp + kx) * 16, 0));
-    }
-    for (int pos = 0; pos < K; ++pos) {
-        int ky, kx;
-        stream_tap(rg, pos, ky, kx);
-        const int dy = ky - g.p0, dx = kx - g.p0;
-        const float pdw = (float)(dy * dy + dx * dx) * pw;
-        float *wt = lds[pos & 1][gl < kWGroups ? gl : 0];
-        int ky1, kx1;
-        stream_tap(rg, pos + 1 < K ? pos + 1 : pos, ky1, kx1);
-        const int toff1 = ky1 * g.Wp + kx1;
+            cur[j] = __builtin_bit_cast(f3, __builtin_amdgcn_raw_buffer_load_b96(irsrc, lane * 16, rowoff[j] + ky * g.Wp * 16, 0));
+        const int dy = ky - g.p0;
+        for (int kx = 0; kx < KS; ++kx) {
+            const int it = ky * KS + kx;
+            const int pos = (int)((colpos >> (4 * kx)) & 15) * KS + ky;
+            const int dx = kx - g.p0;
+            const float pdw = (float)(dy * dy + dx * dx) * pw;
+            float *wt = lds[it & 1];
 #pragma unroll
-        for (int j = 0; j < RPW; ++j) {
-            const f3 nb = nbv[j];
-            nbv[j] = __builtin_bit_cast(f3, __builtin_amdgcn_raw_buffer_load_b96(irsrc, ioff[j], toff1 * 16, 0));
-            const float d0 = cr[j] - nb.x, d1 = cg[j] - nb.y, d2 = cb[j] - nb.z;
-            const float cd = fmaf(d2, d2, fmaf(d1, d1, d0 * d0));
-            if (place[j] >= 0) wt[place[j]] = fmaf(cd, cw, pdw);
-        }
-        __syncthreads();
-        // (two buffers: the next tap writes the other one; the barrier of that tap separates this tap's reads
-        // from the writes of the tap after it)
-        for (int i = tid; i < kWGroups * WQ * 64; i += 256) {
-            const int ol = i & 63, q = (i >> 6) % WQ, gg = i / (64 * WQ);
-            if (gq * kWGroups + gg >= g.NG) continue;
-            const float *src = lds[pos & 1][gg] + ol * WP + 4 * q;
-            f4 v;
+            for (int j = 0; j < RPW; ++j) {
+                f3 nb = cur[j];
+                if ((plain >> j) & 1)
+                    nb = __builtin_bit_cast(f3, __builtin_amdgcn_raw_buffer_load_b96(irsrc, ioff[j], (ky * g.Wp + kx) * 16, 0));
+                const float d0 = cr[j] - nb.x, d1 = cg[j] - nb.y, d2 = cb[j] - nb.z;
+                const float cd = fmaf(d2, d2, fmaf(d1, d1, d0 * d0));
+                if (place[j] >= 0) wt[place[j]] = fmaf(cd, cw, pdw);
+                // the neighbour of the next tap column is the pixel one lane further
+                cur[j].x = shift_left_lane(cur[j].x);
+                cur[j].y = shift_left_lane(cur[j].y);
+                cur[j].z = shift_left_lane(cur[j].z);
+            }
+            __syncthreads();
+            // (two buffers: the next tap writes the other one; the barrier of that tap separates this tap's reads
+            // from the writes of the tap after it)
+            for (int i = tid; i < WG * WQ * 64; i += NT) {
+                const int ol = i & 63, q = (i >> 6) % WQ, gg = i / (64 * WQ);
+                if (gq * WG + gg >= g.NG) continue;
+                const float *src = wt + gg * GST + ol * WP + 4 * q;
+                f4 v;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) v[jj] = 4 * q + jj < KS ? src[jj] : 0.f;
-            float *out = wtab + (unit0 + gg) * (size_t)K * (WQ * 256);
-            *reinterpret_cast<f4 *>(out + ((size_t)(pos * WQ + q) * 64 + ol) * 4) = v;
+                for (int jj = 0; jj < 4; ++jj) v[jj] = 4 * q + jj < KS ? src[jj] : 0.f;
+                float *out = wtab + (unit0 + gg) * (size_t)K * (WQ * 256);
+                *reinterpret_cast<f4 *>(out + ((size_t)(pos * WQ + q) * 64 + ol) * 4) = v;
+            }
         }
     }
 }
@@ -748,9 +778,10 @@ int launch_cfg(const RingArgs &a, int mode, hipStream_t st)
     };
     if (mode == 3) {
         // the weight table of the call
-        const long long wgs = (long long)g.B * g.NBB * ((g.NG + kWGroups - 1) / kWGroups);
+        constexpr int WG = WeightsCfg<KS>::WG;
+        const long long wgs = (long long)g.B * g.NBB * ((g.NG + WG - 1) / WG);
         if (wgs >= (1LL << 31)) return MFL_ERR_TOO_LARGE;
-        hipLaunchKernelGGL(weights_kernel<KS>, dim3((unsigned)wgs), dim3(256), 0, st, a.r, a.ip4, a.pos_w, a.col_w, a.wtab_out);
+        hipLaunchKernelGGL(weights_kernel<KS>, dim3((unsigned)wgs), dim3(64 * WeightsCfg<KS>::NWV), 0, st, a.r, a.ip4, a.pos_w, a.col_w, a.wtab_out);
         return (int)hipGetLastError();
     }
     int rc;
