@@ -13,13 +13,15 @@ F = ctypes.POINTER(ctypes.c_float)
 I = ctypes.POINTER(ctypes.c_int)
 
 CASES = [  # B, C, H, W, k
-    (1, 19, 80, 128, 11),      # 19 labels, 11x11: three channel splits of 7
+    (1, 19, 80, 128, 11),      # 19 labels, 11x11: two channel splits of 10
+    (1, 21, 100, 120, 11),     # 21 labels: three splits of 7
     (1, 8, 40, 100, 11),       # two splits (the minimum), one dummy channel... 8 = 7 + 1
     (2, 21, 80, 96, 9),        # 21 labels, 9x9: three splits of 8
-    (1, 30, 110, 90, 9),       # four splits, one group per workgroup
+    (1, 30, 110, 90, 9),       # three splits of 10
+    (1, 31, 110, 100, 9),      # four splits of 8, one group per workgroup
     (1, 5, 60, 75, 11),        # narrowest supported width for k = 11
     (1, 12, 100, 120, 9),
-    (1, 28, 90, 160, 11),      # four splits of 7
+    (1, 28, 90, 160, 11),      # three splits of 10
 ]
 
 

@@ -154,19 +154,23 @@ SHAPES = [  # B, C, H, W, k
     (1, 4, 31, 29, 1),         # 1x1 window
     # wide enough for the diagonal gather kernels (W >= 64 + k, H*W >= 4*C*k*k)
     (2, 21, 96, 112, 7),       # two channel splits of 11
-    (1, 19, 96, 128, 11),      # wide window: four channel splits of 5
+    (1, 19, 96, 128, 11),      # wide window, stream kernels: two channel splits of 10
     (1, 23, 70, 90, 5),        # three channel splits
     (2, 5, 40, 80, 5),
     (1, 9, 50, 75, 3),
     (1, 32, 90, 100, 3),
-    (1, 12, 100, 120, 9),      # 9x9: three channel splits of 5
+    (1, 12, 100, 120, 9),      # 9x9, stream kernels: two channel splits of 8
     (1, 19, 80, 100, 7),       # two channel splits of 10
     (1, 6, 60, 100, 7),        # one split of 8, eight groups per workgroup
     (1, 14, 64, 96, 5),        # two splits of 8
     (1, 16, 64, 96, 7),
     (1, 28, 80, 96, 5),        # three splits of 10
-    (1, 4, 60, 100, 11),       # wide windows: one split of 5
-    (1, 8, 64, 100, 9),        # ... two splits of 5
+    (1, 4, 60, 100, 11),       # wide windows: one live split of 7 (and an idle one)
+    (1, 8, 64, 100, 9),        # ... of 8
+    (1, 19, 90, 120, 9),       # 9x9: two splits of 10
+    (1, 25, 96, 128, 11),      # 11x11: three splits of 10
+    (1, 31, 110, 140, 11),     # 11x11: four splits of 10, one group per workgroup
+    (1, 21, 100, 120, 11),     # 11x11: three splits of 7
     (1, 5, 35, 81, 3),         # a last b-block of 1 live lane: its pixels go to the tail kernel
     (2, 8, 130, 200, 5),       # ... of 6 live lanes
     (1, 17, 64, 70, 3),        # barely wide enough: most steps meet a row start (records with more flagged steps than slots)
