@@ -618,6 +618,48 @@ bool diag_eligible(int op, int B, int C, int H, int W, int k, DiagGeom &g)
     return make_diag_geom(g, B, C, H, W, k, kDiagWeightLds, op != MFL_OP_LOCAL_BACKWARD) == 0;
 }
 
+// More than 33 labels: the diagonal kernels compute the window sums block by block of output channels (every
+// block reads all input planes; one address table per block), for the mean-field loop whose label step runs as
+// a separate kernel anyway.  All b-blocks run as regular workgroups (no tail workgroups).
+struct BlockWorkspace {
+    size_t xp, xp2, ip4, table, groups, msg, total;
+    size_t table_stride;                      // bytes between the tables of consecutive blocks
+    int nblk;
+};
+
+bool diag_block_eligible(int B, int C, int H, int W, int k, DiagGeom &g)
+{
+    if (C <= 33) return false;
+    return make_diag_geom(g, B, C, H, W, k, kDiagWeightLds, false, diag_block_width(C)) == 0;
+}
+
+BlockWorkspace block_carve(const DiagGeom &g)
+{
+    BlockWorkspace w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    take(kTagBytes);                                  // plan tag
+    w.nblk = (g.C + g.Cb - 1) / g.Cb;
+    w.xp = take(diag_padded_floats(g) * 4);
+    w.xp2 = take(diag_padded_floats(g) * 4);
+    w.ip4 = take(((size_t)g.B * g.plane + 64) * sizeof(F4));
+    w.table_stride = align_up(diag_table_dwords(g) * 4, 256);
+    w.table = take(w.table_stride * w.nblk);
+    w.groups = take((size_t)g.k * g.k * 4);
+    w.msg = take((size_t)g.B * g.C * g.L * 4);
+    w.total = off;
+    return w;
+}
+
+// The geometry of block `blk` of a block geometry.
+DiagGeom block_geom(const DiagGeom &g, int blk)
+{
+    DiagGeom b = g;
+    b.c0 = blk * g.Cb;
+    b.Cv = g.C - b.c0 < g.Cb ? g.C - b.c0 : g.Cb;
+    return b;
+}
+
 int dispatch_diag(const DiagArgs &a, int mode, hipStream_t st)
 {
 #define MFL_DIAG_CASE(CHV, KSV) \
@@ -849,7 +891,12 @@ size_t mfl_workspace_bytes(int op, int B, int C, int H, int W, int k, int iters)
     if (diag && op != MFL_OP_LOCAL_BACKWARD) return diag_carve(op, dg).total;
     Geom g;
     if (make_geom(g, B, C, H, W, k, 1)) return 0;
-    const size_t generic = carve(op, g, pick_cc(C)).total;
+    size_t generic = carve(op, g, pick_cc(C)).total;
+    if (op == MFL_OP_MEANFIELD_FORWARD && diag_block_eligible(B, C, H, W, k, dg)) {
+        // (with a label matrix the loop takes the diagonal kernels block by block, without one the generic ones)
+        const size_t blocks = block_carve(dg).total;
+        if (blocks > generic) generic = blocks;
+    }
     // the backward takes the diagonal kernels with an image and the generic ones with a cd tensor
     if (diag) { const size_t d = diag_carve(op, dg).total; return d > generic ? d : generic; }
     return generic;
@@ -1083,6 +1130,63 @@ static int meanfield_forward_impl(const float *unary, const float *img, const fl
             da.qp_out = qb;
             da.logq = out_of(it);
             rc = dispatch_diag(da, 0, st);
+            if (rc) return rc;
+            float *t = qa; qa = qb; qb = t;
+        }
+        return MFL_OK;
+    }
+    DiagGeom bg;
+    if (C > 32 && compat && mfl::label_step_supported(C) && mfl::label_step_fits(B, C, H, W, k) &&
+        diag_block_eligible(B, C, H, W, k, bg)) {
+        // 33 .. 160 labels: window sums on the diagonal kernels, one launch per block of output channels, then the
+        // label step (affine, label product on the matrix cores, normalise) as one kernel
+        const BlockWorkspace ws = block_carve(bg);
+        if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
+        char *base = (char *)workspace;
+        float *qa = (float *)(base + ws.xp), *qb = (float *)(base + ws.xp2);
+        F4 *ip4 = (F4 *)(base + ws.ip4);
+        uint32_t *groups = (uint32_t *)(base + ws.groups);
+        float *msg = (float *)(base + ws.msg);
+        hipStream_t st = (hipStream_t)stream;
+        const size_t n = (size_t)bg.B * bg.C * bg.plane;
+        MFL_CHECK_HIP(hipMemsetAsync(qa, 0, (size_t)bg.FS * 4, st));
+        hipLaunchKernelGGL(pad_planes_kernel, dim3(pad_rows_grid((size_t)bg.B * bg.C * bg.Hp)), dim3(kThreads), 0, st, unary, qa + bg.FS,
+                           bg.B * bg.C, bg.H, bg.W, bg.Hp, bg.Wp, bg.p0);                  // Q_0 = unary, padded
+        MFL_CHECK_HIP(hipMemsetAsync(qa + bg.FS + n, 0, (3 * (size_t)bg.Wp + 64) * 4, st));
+        const size_t ni = (size_t)bg.B * bg.plane;
+        hipLaunchKernelGGL(pad_image4_kernel, dim3(grid_for(ni)), dim3(kThreads), 0, st, img, ip4, bg.B, bg.H, bg.W, bg.Hp, bg.Wp, bg.p0);
+        MFL_CHECK_HIP(hipMemsetAsync(ip4 + ni, 0, 64 * sizeof(F4), st));
+        {
+            // the address tables of all blocks, unless the workspace holds them already
+            uint32_t *tag = (uint32_t *)workspace;
+            const PlanTag want = make_tag(4, MFL_OP_MEANFIELD_FORWARD, bg.B, bg.C, bg.H, bg.W, bg.k);
+            hipLaunchKernelGGL(diag_groups_kernel, dim3(1), dim3(64), 0, st, bg, groups, tag, want);
+            const size_t nrec = (size_t)bg.NBB * bg.NG * bg.K * bg.NCS;
+            const unsigned blocks = (unsigned)((nrec + 255) / 256 < 65535u * 8 ? (nrec + 255) / 256 : 65535u * 8);
+            for (int blk = 0; blk < ws.nblk; ++blk)
+                hipLaunchKernelGGL(diag_table_kernel, dim3(blocks), dim3(256), 0, st, block_geom(bg, blk),
+                                   (uint32_t *)(base + ws.table + blk * ws.table_stride), tag, want);
+            hipLaunchKernelGGL(stamp_tag_kernel, dim3(1), dim3(64), 0, st, tag, want);
+            rc = (int)hipGetLastError();
+            if (rc) return rc;
+        }
+        MFL_CHECK_HIP(hipMemsetAsync(qb, 0, diag_padded_floats(bg) * 4, st));   // borders of the other buffer
+        DiagArgs da{};
+        diag_lds(bg, da);
+        da.ip4 = ip4;
+        da.groups = groups;
+        da.pos_w = pos_w;
+        da.col_w = col_w;
+        da.y = msg;
+        for (int it = 0; it < iters; ++it) {
+            da.xp = qa;
+            for (int blk = 0; blk < ws.nblk; ++blk) {
+                da.g = block_geom(bg, blk);
+                da.table = (const uint32_t *)(base + ws.table + blk * ws.table_stride);
+                rc = dispatch_diag(da, 1, st);                                    // msg = Q_t * window sums
+                if (rc) return rc;
+            }
+            rc = mfl::launch_label_step(msg, affine_w, affine_b, compat, unary, out_of(it), qb + bg.FS, k, B, C, H, W, st);
             if (rc) return rc;
             float *t = qa; qa = qb; qb = t;
         }

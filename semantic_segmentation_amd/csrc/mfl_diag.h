@@ -40,6 +40,9 @@ namespace mfl {
 
 struct DiagGeom {
     int B, C, H, W, k, K, p0;
+    int c0, Cb, Cv;           // output channels of a launch: [c0, c0 + Cv) of a block of width Cb (the split is made for
+                              // Cb); c0 = 0, Cb = Cv = C unless the channels are computed block by block (more labels
+                              // than one workgroup's waves hold)
     int L, CK;
     int Hp, Wp, plane, gap;   // zero-padded plane; gap = Wp - W = k - 1
     int NB;                   // number of b values: ceil(L / CK)
@@ -86,14 +89,24 @@ inline bool diag_split(int C, int k, int &CH, int &NCS, int &NGW)
     return true;
 }
 
-inline bool diag_supported(int C, int H, int W, int k)
+// cb: channels one launch computes (all C of them unless the channels are computed block by block)
+inline bool diag_supported(int C, int H, int W, int k, int cb = 0)
 {
+    if (cb <= 0) cb = C;
     if (!(k == 3 || k == 5 || k == 7 || k == 9 || k == 11)) return false;
-    if (C > 33 || W < 64 + k || W >= 16384) return false;
+    if (cb > 33 || cb > C || W < 64 + k || W >= 16384) return false;
     const long long CK = (long long)C * k * k, L = (long long)H * W;
     if (L < 4 * CK) return false;   // too few source pixels per row of the scrambled matrix to fill a wave
     int ch, ncs, ngw;
-    return diag_split(C, k, ch, ncs, ngw);
+    return diag_split(cb, k, ch, ncs, ngw);
+}
+
+// Width of the channel blocks for C > 33 labels: the fewest blocks of at most 22 channels (two waves of 11 per
+// group and four groups per workgroup, the fastest split measured), equal widths.
+inline int diag_block_width(int C)
+{
+    const int nblk = (C + 21) / 22;
+    return (C + nblk - 1) / nblk;
 }
 
 // Table record of one (b-block, group, tap, channel split), in dwords (at most 64, so that one
@@ -122,10 +135,11 @@ MFL_HD int diag_recw(int CH) { return ((diag_xw_base(CH) + (CH + 1) / 2 + 3) / 4
 constexpr int kDiagTailLanes = 16;
 
 // Returns 0 on success, -1 invalid, -3 too large for 32-bit indexing.
-inline int make_diag_geom(DiagGeom &g, int B, int C, int H, int W, int k, int lds_budget_bytes, bool allow_tail = true)
+inline int make_diag_geom(DiagGeom &g, int B, int C, int H, int W, int k, int lds_budget_bytes, bool allow_tail = true, int cb = 0)
 {
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0) return -1;
-    if (!diag_supported(C, H, W, k)) return -1;
+    if (cb <= 0) cb = C;
+    if (!diag_supported(C, H, W, k, cb)) return -1;
     const long long K = (long long)k * k, L = (long long)H * W, CK = (long long)C * K;
     const long long Hp = (long long)H + k - 1, Wp = (long long)W + k - 1, plane = Hp * Wp;
     if (L >= (1LL << 30) || (C * plane + 4 * Wp + 256) * 4 >= (1LL << 31)) return -3;
@@ -133,6 +147,7 @@ inline int make_diag_geom(DiagGeom &g, int B, int C, int H, int W, int k, int ld
     // very large images: the planes pass the check above and the image does not)
     if ((plane + (long long)k * Wp + 64) * 16 >= (1LL << 31)) return -3;
     g.B = B; g.C = C; g.H = H; g.W = W; g.k = k; g.K = (int)K; g.p0 = k / 2;
+    g.c0 = 0; g.Cb = cb; g.Cv = cb;
     g.L = (int)L; g.CK = (int)CK; g.Hp = (int)Hp; g.Wp = (int)Wp; g.plane = (int)plane; g.gap = k - 1;
     g.NB = (int)((L + CK - 1) / CK);
     g.NG = C * k;
@@ -148,7 +163,7 @@ inline int make_diag_geom(DiagGeom &g, int B, int C, int H, int W, int k, int ld
             g.NBB -= 1;
         }
     }
-    diag_split(C, k, g.CH, g.NCS, g.NGW);
+    diag_split(cb, k, g.CH, g.NCS, g.NGW);
     g.NGB = (g.NG + g.NGW - 1) / g.NGW;
     g.RUN = g.NGW * k;
     g.RUNP = (g.RUN & 1) ? g.RUN + 2 : g.RUN + 1;
@@ -260,9 +275,9 @@ MFL_HD void diag_fill_record(const DiagGeom &g, int beta, int gamma, int t, int 
     for (int i = 0; i < g.RECW; ++i) rec[i] = 0;
     for (int i = 0; i < g.CH; ++i) {
         int c = ci * g.CH + i;
-        const bool dummy = c >= g.C;
-        if (dummy) c = ci * g.CH < g.C ? ci * g.CH : 0;
-        const DiagStep st = diag_step(g, beta, gamma, t, c);
+        const bool dummy = c >= g.Cv;
+        if (dummy) c = ci * g.CH < g.Cv ? ci * g.CH : 0;
+        const DiagStep st = diag_step(g, beta, gamma, t, g.c0 + c);
         int tA, tB, oA, oB;
         diag_side(g, st.offA, st.xA, tA, oA);
         diag_side(g, st.offB, st.xB, tB, oB);

@@ -731,10 +731,11 @@ diag_kernel(DiagGeom g, int epi_rows, int tail_per_group, const float *__restric
 #endif
                 int moff, l, cpos;
                 if (!place(cb0, r, moff, l, cpos)) continue;
+                // (the launch's channels: all of them, or one block [c0, c0 + Cv) of a larger label set)
                 const float *msg = lds + moff;
-                const float *qc = in_b + g.FS + cpos;
-                float *y_b = y_out + (size_t)img * C * L + l;
-                for (int c = 0; c < C; ++c)
+                const float *qc = in_b + g.FS + cpos + (size_t)g.c0 * g.plane;
+                float *y_b = y_out + ((size_t)img * C + g.c0) * L + l;
+                for (int c = 0; c < g.Cv; ++c)
                     y_b[(size_t)c * L] = MODE == 1 ? msg[c * cstride] * qc[(size_t)c * g.plane] : msg[c * cstride];
             }
             __syncthreads();

@@ -85,6 +85,7 @@ inline int make_ring_geom(RingGeom &r, int B, int C, int H, int W, int k)
     if (L >= (1LL << 30) || (C * plane + 4 * Wp + 256) * 4 >= (1LL << 31)) return -3;
     if ((plane + (long long)k * Wp + 64) * 16 >= (1LL << 31)) return -3;
     g.B = B; g.C = C; g.H = H; g.W = W; g.k = k; g.K = (int)K; g.p0 = k / 2;
+    g.c0 = 0; g.Cb = C; g.Cv = C;
     g.L = (int)L; g.CK = (int)CK; g.Hp = (int)Hp; g.Wp = (int)Wp; g.plane = (int)plane; g.gap = k - 1;
     g.NB = (int)((L + CK - 1) / CK);
     g.NG = C * k;

@@ -294,6 +294,26 @@ def test_label_step_channel_block_counts_vs_oracle(C, S, oracle):
     assert strict_rel_err_on_marginals(lq, ref) < RTOL
 
 
+@pytest.mark.parametrize("shape", [(1, 150, 176, 180, 7),      # seven blocks of output channels (six of 22, one of 18)
+                                   (2, 70, 100, 90, 5),        # blocks of 18, 18, 18 and 16 channels
+                                   (1, 40, 96, 100, 3)])       # two blocks of 20
+def test_many_labels_channel_blocks_vs_oracle(shape, S, oracle):
+    """More than 33 labels on images wide and large enough for the diagonal kernels (W >= 64 + k, H*W >= 4*C*k*k):
+    the window sums are computed block by block of output channels, then the fused label step; against the C oracle."""
+    B, C, H, W, k = shape
+    unary, img, _ = make_inputs(shape, 71)
+    rng = np.random.default_rng(72)
+    compat = ((1 - np.eye(C)) + 0.01 * rng.standard_normal((C, C))).astype(np.float32) / 8
+    aw = (1 + 0.2 * rng.standard_normal((1, C, H, W))).astype(np.float32)
+    ab = (0.1 * rng.standard_normal((1, C, H, W))).astype(np.float32)
+    for iters, affine in ((1, False), (2, True)):
+        lq = host(S.ops.meanfield_forward(dev(unary), dev(img), scalar(-0.004), scalar(-0.003), k, iters,
+                                          dev(aw) if affine else None, dev(ab) if affine else None, dev(compat)))
+        ref = oracle.meanfield_forward(unary, img, -0.004, -0.003, k, iters, aw if affine else None, ab if affine else None, compat)
+        assert_close(lq, ref, RTOL, f"logq iters={iters}")
+        assert strict_rel_err_on_marginals(lq, ref) < RTOL
+
+
 def test_150_labels_full_size_properties(S):
     """150 labels, 512x512 (BASELINE config 5 image size), batch 2: marginals sum to one, and an image's result
     does not depend on what else is in the batch."""
