@@ -633,7 +633,7 @@ bool diag_block_eligible(int B, int C, int H, int W, int k, DiagGeom &g)
     return make_diag_geom(g, B, C, H, W, k, kDiagWeightLds, false, diag_block_width(C)) == 0;
 }
 
-BlockWorkspace block_carve(const DiagGeom &g)
+BlockWorkspace block_carve(int op, const DiagGeom &g)
 {
     BlockWorkspace w{};
     size_t off = 0;
@@ -641,12 +641,12 @@ BlockWorkspace block_carve(const DiagGeom &g)
     take(kTagBytes);                                  // plan tag
     w.nblk = (g.C + g.Cb - 1) / g.Cb;
     w.xp = take(diag_padded_floats(g) * 4);
-    w.xp2 = take(diag_padded_floats(g) * 4);
+    if (op == MFL_OP_MEANFIELD_FORWARD) w.xp2 = take(diag_padded_floats(g) * 4);
     w.ip4 = take(((size_t)g.B * g.plane + 64) * sizeof(F4));
     w.table_stride = align_up(diag_table_dwords(g) * 4, 256);
     w.table = take(w.table_stride * w.nblk);
     w.groups = take((size_t)g.k * g.k * 4);
-    w.msg = take((size_t)g.B * g.C * g.L * 4);
+    if (op == MFL_OP_MEANFIELD_FORWARD) w.msg = take((size_t)g.B * g.C * g.L * 4);
     w.total = off;
     return w;
 }
@@ -702,6 +702,55 @@ void diag_lds(const DiagGeom &g, DiagArgs &a)
     const int rows = (g.NBR + chunks - 1) / chunks;
     a.lds_bytes = lds;
     a.epi_rows = rows;
+}
+
+// Pads x (planes) into xp and img into ip4 and builds the address tables of all channel blocks (unless the
+// workspace holds them already).
+int block_prepare(int op, void *workspace, const DiagGeom &bg, const BlockWorkspace &ws, const float *x, const float *img,
+                  float *xp, hipStream_t st)
+{
+    char *base = (char *)workspace;
+    F4 *ip4 = (F4 *)(base + ws.ip4);
+    const size_t n = (size_t)bg.B * bg.C * bg.plane;
+    MFL_CHECK_HIP(hipMemsetAsync(xp, 0, (size_t)bg.FS * 4, st));
+    hipLaunchKernelGGL(pad_planes_kernel, dim3(pad_rows_grid((size_t)bg.B * bg.C * bg.Hp)), dim3(kThreads), 0, st, x, xp + bg.FS,
+                       bg.B * bg.C, bg.H, bg.W, bg.Hp, bg.Wp, bg.p0);
+    MFL_CHECK_HIP(hipMemsetAsync(xp + bg.FS + n, 0, (3 * (size_t)bg.Wp + 64) * 4, st));
+    const size_t ni = (size_t)bg.B * bg.plane;
+    hipLaunchKernelGGL(pad_image4_kernel, dim3(grid_for(ni)), dim3(kThreads), 0, st, img, ip4, bg.B, bg.H, bg.W, bg.Hp, bg.Wp, bg.p0);
+    MFL_CHECK_HIP(hipMemsetAsync(ip4 + ni, 0, 64 * sizeof(F4), st));
+    uint32_t *tag = (uint32_t *)workspace;
+    const PlanTag want = make_tag(4, op, bg.B, bg.C, bg.H, bg.W, bg.k);
+    hipLaunchKernelGGL(diag_groups_kernel, dim3(1), dim3(64), 0, st, bg, (uint32_t *)(base + ws.groups), tag, want);
+    const size_t nrec = (size_t)bg.NBB * bg.NG * bg.K * bg.NCS;
+    const unsigned blocks = (unsigned)((nrec + 255) / 256 < 65535u * 8 ? (nrec + 255) / 256 : 65535u * 8);
+    for (int blk = 0; blk < ws.nblk; ++blk)
+        hipLaunchKernelGGL(diag_table_kernel, dim3(blocks), dim3(256), 0, st, block_geom(bg, blk),
+                           (uint32_t *)(base + ws.table + blk * ws.table_stride), tag, want);
+    hipLaunchKernelGGL(stamp_tag_kernel, dim3(1), dim3(64), 0, st, tag, want);
+    return (int)hipGetLastError();
+}
+
+// y = x * window sums of the padded planes xp, one launch per channel block.
+int block_window_products(void *workspace, const DiagGeom &bg, const BlockWorkspace &ws, const float *xp, const float *pos_w,
+                          const float *col_w, float *y, hipStream_t st)
+{
+    char *base = (char *)workspace;
+    DiagArgs da{};
+    diag_lds(bg, da);
+    da.xp = xp;
+    da.ip4 = (const F4 *)(base + ws.ip4);
+    da.groups = (const uint32_t *)(base + ws.groups);
+    da.pos_w = pos_w;
+    da.col_w = col_w;
+    da.y = y;
+    for (int blk = 0; blk < ws.nblk; ++blk) {
+        da.g = block_geom(bg, blk);
+        da.table = (const uint32_t *)(base + ws.table + blk * ws.table_stride);
+        const int rc = dispatch_diag(da, 1, st);
+        if (rc) return rc;
+    }
+    return MFL_OK;
 }
 
 
@@ -892,9 +941,10 @@ size_t mfl_workspace_bytes(int op, int B, int C, int H, int W, int k, int iters)
     Geom g;
     if (make_geom(g, B, C, H, W, k, 1)) return 0;
     size_t generic = carve(op, g, pick_cc(C)).total;
-    if (op == MFL_OP_MEANFIELD_FORWARD && diag_block_eligible(B, C, H, W, k, dg)) {
-        // (with a label matrix the loop takes the diagonal kernels block by block, without one the generic ones)
-        const size_t blocks = block_carve(dg).total;
+    if (op != MFL_OP_LOCAL_BACKWARD && diag_block_eligible(B, C, H, W, k, dg)) {
+        // (more than 33 labels: the diagonal kernels block by block with an image, and in the loop with a label
+        // matrix; the generic ones otherwise)
+        const size_t blocks = block_carve(op, dg).total;
         if (blocks > generic) generic = blocks;
     }
     // the backward takes the diagonal kernels with an image and the generic ones with a cd tensor
@@ -960,6 +1010,16 @@ int mfl_local_forward(const float *x, const float *img, const float *cd, const f
         da.col_w = col_w;
         da.y = y;
         return dispatch_diag(da, 1, st);
+    }
+    if (img && diag_block_eligible(B, C, H, W, k, dg)) {
+        // more than 33 labels: the diagonal kernels, one launch per block of output channels
+        const BlockWorkspace ws = block_carve(MFL_OP_LOCAL_FORWARD, dg);
+        if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
+        hipStream_t st = (hipStream_t)stream;
+        float *xp = (float *)((char *)workspace + ws.xp);
+        rc = block_prepare(MFL_OP_LOCAL_FORWARD, workspace, dg, ws, x, img, xp, st);
+        if (rc) return rc;
+        return block_window_products(workspace, dg, ws, xp, pos_w, col_w, y, st);
     }
     Geom g;
     int cc;
@@ -1140,52 +1200,18 @@ static int meanfield_forward_impl(const float *unary, const float *img, const fl
         diag_block_eligible(B, C, H, W, k, bg)) {
         // 33 .. 160 labels: window sums on the diagonal kernels, one launch per block of output channels, then the
         // label step (affine, label product on the matrix cores, normalise) as one kernel
-        const BlockWorkspace ws = block_carve(bg);
+        const BlockWorkspace ws = block_carve(MFL_OP_MEANFIELD_FORWARD, bg);
         if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
         char *base = (char *)workspace;
         float *qa = (float *)(base + ws.xp), *qb = (float *)(base + ws.xp2);
-        F4 *ip4 = (F4 *)(base + ws.ip4);
-        uint32_t *groups = (uint32_t *)(base + ws.groups);
         float *msg = (float *)(base + ws.msg);
         hipStream_t st = (hipStream_t)stream;
-        const size_t n = (size_t)bg.B * bg.C * bg.plane;
-        MFL_CHECK_HIP(hipMemsetAsync(qa, 0, (size_t)bg.FS * 4, st));
-        hipLaunchKernelGGL(pad_planes_kernel, dim3(pad_rows_grid((size_t)bg.B * bg.C * bg.Hp)), dim3(kThreads), 0, st, unary, qa + bg.FS,
-                           bg.B * bg.C, bg.H, bg.W, bg.Hp, bg.Wp, bg.p0);                  // Q_0 = unary, padded
-        MFL_CHECK_HIP(hipMemsetAsync(qa + bg.FS + n, 0, (3 * (size_t)bg.Wp + 64) * 4, st));
-        const size_t ni = (size_t)bg.B * bg.plane;
-        hipLaunchKernelGGL(pad_image4_kernel, dim3(grid_for(ni)), dim3(kThreads), 0, st, img, ip4, bg.B, bg.H, bg.W, bg.Hp, bg.Wp, bg.p0);
-        MFL_CHECK_HIP(hipMemsetAsync(ip4 + ni, 0, 64 * sizeof(F4), st));
-        {
-            // the address tables of all blocks, unless the workspace holds them already
-            uint32_t *tag = (uint32_t *)workspace;
-            const PlanTag want = make_tag(4, MFL_OP_MEANFIELD_FORWARD, bg.B, bg.C, bg.H, bg.W, bg.k);
-            hipLaunchKernelGGL(diag_groups_kernel, dim3(1), dim3(64), 0, st, bg, groups, tag, want);
-            const size_t nrec = (size_t)bg.NBB * bg.NG * bg.K * bg.NCS;
-            const unsigned blocks = (unsigned)((nrec + 255) / 256 < 65535u * 8 ? (nrec + 255) / 256 : 65535u * 8);
-            for (int blk = 0; blk < ws.nblk; ++blk)
-                hipLaunchKernelGGL(diag_table_kernel, dim3(blocks), dim3(256), 0, st, block_geom(bg, blk),
-                                   (uint32_t *)(base + ws.table + blk * ws.table_stride), tag, want);
-            hipLaunchKernelGGL(stamp_tag_kernel, dim3(1), dim3(64), 0, st, tag, want);
-            rc = (int)hipGetLastError();
-            if (rc) return rc;
-        }
+        rc = block_prepare(MFL_OP_MEANFIELD_FORWARD, workspace, bg, ws, unary, img, qa, st);      // Q_0 = unary, padded
+        if (rc) return rc;
         MFL_CHECK_HIP(hipMemsetAsync(qb, 0, diag_padded_floats(bg) * 4, st));   // borders of the other buffer
-        DiagArgs da{};
-        diag_lds(bg, da);
-        da.ip4 = ip4;
-        da.groups = groups;
-        da.pos_w = pos_w;
-        da.col_w = col_w;
-        da.y = msg;
         for (int it = 0; it < iters; ++it) {
-            da.xp = qa;
-            for (int blk = 0; blk < ws.nblk; ++blk) {
-                da.g = block_geom(bg, blk);
-                da.table = (const uint32_t *)(base + ws.table + blk * ws.table_stride);
-                rc = dispatch_diag(da, 1, st);                                    // msg = Q_t * window sums
-                if (rc) return rc;
-            }
+            rc = block_window_products(workspace, bg, ws, qa, pos_w, col_w, msg, st);              // msg = Q_t * window sums
+            if (rc) return rc;
             rc = mfl::launch_label_step(msg, affine_w, affine_b, compat, unary, out_of(it), qb + bg.FS, k, B, C, H, W, st);
             if (rc) return rc;
             float *t = qa; qa = qb; qb = t;

@@ -174,6 +174,8 @@ SHAPES = [  # B, C, H, W, k
     (1, 5, 35, 81, 3),         # a last b-block of 1 live lane: its pixels go to the tail kernel
     (2, 8, 130, 200, 5),       # ... of 6 live lanes
     (1, 17, 64, 70, 3),        # barely wide enough: most steps meet a row start (records with more flagged steps than slots)
+    (1, 40, 96, 100, 3),       # more than 33 labels on the diagonal kernels: two blocks of 20 output channels
+    (2, 70, 100, 90, 5),       # ... blocks of 18, 18, 18 and 16
 ]
 DIAG_SHAPES = SHAPES[10:]
 
