@@ -8,8 +8,8 @@
 // starts (threshold T, "shared" and "extra" element): header comment and diag_side in mfl_diag.h.
 //
 // ---- what changes against the first diagonal kernels ---------------------------------------------
-// Every wave is an independent stream: it computes the tap weights of its own 64 x k pixels (no
-// workgroup barrier in the tap loop), reads one table record per tap with scalar loads, and keeps the
+// Every wave is a stream of its own: it takes the tap weights of its own 64 x k pixels from the call's weight
+// table, reads one table record per tap with scalar loads, and keeps the
 // shared elements (A, B) of the next tap in flight in registers that are refilled in place.  A step
 // that meets an image-row start needs, per side, the element gap floats further ("extra") for a few
 // lanes: that is the element lane + gap of the same load, fetched with a lane permute.  For it to
@@ -26,6 +26,9 @@
 //   [CH, 2CH)      the same for side B
 //   [2CH, ...)     16 bits per step: (TA + 64) | (TB + 64) << 8; a step with both thresholds 64 meets
 //                  no image-row start
+//   then one word  bit s: step s of the NEXT stream position meets an image-row start, so the lanes past BL
+//                  must load along for it (their elements are the "extra" ones); otherwise only the BL owning
+//                  lanes request elements (a shorter run touches fewer cache lines)
 #ifndef MFL_RING_H
 #define MFL_RING_H
 
@@ -71,7 +74,7 @@ inline bool ring_supported(int C, int H, int W, int k)
     return ring_split(C, k, ch, ncs, ngw);
 }
 
-MFL_HD int ring_recw(int CH) { return ((2 * CH + (CH + 1) / 2 + 3) / 4) * 4; }
+MFL_HD int ring_recw(int CH) { return ((2 * CH + (CH + 1) / 2 + 1 + 3) / 4) * 4; }
 
 // Returns 0 on success, -1 invalid / unsupported, -3 too large for 32-bit indexing.
 inline int make_ring_geom(RingGeom &r, int B, int C, int H, int W, int k)
@@ -169,6 +172,22 @@ MFL_HD void ring_fill_record(const RingGeom &r, int beta, int gamma, int i, int 
         const uint32_t t16 = (uint32_t)(tA + 64) | ((uint32_t)(tB + 64) << 8);
         rec[2 * g.CH + s / 2] |= t16 << (16 * (s & 1));
     }
+    // which steps of the next position (position K repeats K - 1) meet an image-row start
+    uint32_t next = ~0u;
+    if (i < g.K) {
+        next = 0;
+        const int tn = ring_stream_tap(r, i + 1 < g.K ? i + 1 : g.K - 1);
+        for (int s = 0; s < g.CH; ++s) {
+            int c = ci * g.CH + s;
+            if (c >= g.C) c = ci * g.CH < g.C ? ci * g.CH : 0;
+            const DiagStep st = diag_step(g, beta, gamma, tn, c);
+            int tA, tB, oA, oB;
+            diag_side(g, st.offA, st.xA, tA, oA);
+            diag_side(g, st.offB, st.xB, tB, oB);
+            if (tA != 64 || tB != 64) next |= 1u << s;
+        }
+    }
+    rec[2 * g.CH + (g.CH + 1) / 2] = next;
 }
 
 }  // namespace mfl

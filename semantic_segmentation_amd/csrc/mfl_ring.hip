@@ -4,8 +4,11 @@
 // mfl_ring.h.  One translation unit per (CH, KS): compile with -DMFL_RING_CH= -DMFL_RING_KS=.
 //
 // One workgroup = NGW consecutive groups x NCS channel splits (one wave each) of one b-block of one
-// image.  In the tap loop every wave is on its own (no workgroup barrier, no LDS traffic).  Per stream
-// tap a wave
+// image.  In the tap loop the waves exchange nothing (no LDS traffic); one barrier per tap keeps them in
+// step so that the cache lines they have in common (the weights of a group, overlapping element runs of
+// neighbouring groups) are requested from the L2 once per workgroup.  The kernel is bound by the number of
+// cache-line requests a CU can keep in flight, so lanes that own no pixels request nothing (their buffer
+// offset is out of range), and a tap of alignment class 0 requests no side B.  Per stream tap a wave
 //   - holds the k weights of each lane's pixels in registers, loaded a tap ahead from the weight table
 //     (lane-major, 16 bytes per lane and load: full cache lines); the table is written once per call by
 //     weights_kernel (the weights pd*pos_w + col_w*|I(l) - I(l + tap)|^2 do not change between the
@@ -68,7 +71,7 @@ struct RingCfg {
     static constexpr int BL = 65 - KS;                            // lanes of a wave that own pixels
     static constexpr int NBR = BL + KS - 1;                       // b rows of a workgroup's tile (= 64)
     static constexpr int WQ = (KS + 3) / 4;                       // 16-byte pieces of a lane's k weights
-    static constexpr int RECW = ((2 * CH + (CH + 1) / 2 + 3) / 4) * 4;
+    static constexpr int RECW = ((2 * CH + (CH + 1) / 2 + 1 + 3) / 4) * 4;
     static constexpr int CE = CH * NCS;
 };
 
@@ -82,6 +85,7 @@ struct Offsets {
 template <int CH>
 struct Thresholds {
     uint32_t w[(CH + 1) / 2];
+    uint32_t next;                          // bit s: step s of the next tap meets an image-row start
 };
 
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, int voff, uint32_t soff)
@@ -162,6 +166,7 @@ struct Loop {
     {
 #pragma unroll
         for (int j = 0; j < (CH + 1) / 2; ++j) thr.w[j] = p[2 * CH + j];
+        thr.next = p[2 * CH + (CH + 1) / 2];
     }
 
     // One gather step: pixels n < KS - SA take side A, the others side B.
@@ -212,16 +217,20 @@ struct Loop {
 #endif
     }
 
-    template <int SA, int STEP>
+    // NEXT_B: the next tap reads side B (a tap of class 0 does not: all its pixels take side A)
+    template <int SA, int STEP, bool NEXT_B>
     __device__ __forceinline__ void steps(const Weights<KS> &w)
     {
         step<SA, STEP>(w);
 #ifndef MFL_ABL_NO_GLOADS
-        // the next tap's elements into the registers this step has just consumed
-        ab[STEP].x = buf_load(rsrc, lane * 4, offn.a[STEP]);
-        ab[STEP].y = buf_load(rsrc, lane * 4, offn.b[STEP]);
+        // the next tap's elements into the registers this step has just consumed; the lanes past BL own no
+        // pixels and load along only where the next tap's step needs their elements as "extra" ones
+        // (an offset out of the descriptor's range: the lane gets 0 and sends no request)
+        const int gvoff = ((thr.next >> STEP) & 1) ? lane * 4 : (lane < Cfg::BL ? lane * 4 : (int)0x80000000u);
+        ab[STEP].x = buf_load(rsrc, gvoff, offn.a[STEP]);
+        if constexpr (NEXT_B) ab[STEP].y = buf_load(rsrc, gvoff, offn.b[STEP]);
 #endif
-        if constexpr (STEP + 1 < CH) steps<SA, STEP + 1>(w);
+        if constexpr (STEP + 1 < CH) steps<SA, STEP + 1, NEXT_B>(w);
     }
 
     // The k weights of the lane's pixels at stream position i (positions past the end repeat the last one).
@@ -233,9 +242,12 @@ struct Loop {
         for (int n = 0; n < KS; ++n) w.set(n, (float)(ic + n));
         return;
 #endif
+        // (the lanes past BL own no pixels: their offset is out of the descriptor's range, which returns 0 without
+        // a memory request, so a piece is 7 cache lines instead of 8; no branch, the wait counts stay exact)
+        const int wvoff = lane < Cfg::BL ? lane * 16 : (int)0x80000000u;
 #pragma unroll
         for (int q = 0; q < Cfg::WQ; ++q) {
-            const f4 v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16, (ic * Cfg::WQ + q) * 1024, MFL_NT_W));
+            const f4 v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, (ic * Cfg::WQ + q) * 1024, MFL_NT_W));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (4 * q + j < KS) w.set(4 * q + j, v[j]);
@@ -243,7 +255,7 @@ struct Loop {
     }
 
     // One tap of alignment class SA at stream position `pos` with the weights `w` (loaded a tap ago).
-    template <int SA>
+    template <int SA, bool NEXT_B = true>
     __device__ __forceinline__ void tap(Weights<KS> &w)
     {
         MFL_SEG(5);
@@ -251,6 +263,14 @@ struct Loop {
         // element offsets of the tap after it (the stream's last record repeats itself)
         constexpr int K = KS * KS;
         Weights<KS> wn;
+        // The waves of a workgroup start a tap together: the channel splits of a group request the same weights
+        // and neighbouring groups overlapping element runs (side B of one is side A of the next, k floats
+        // further), so whoever comes second finds the cache lines in the CU's L1 (32 KB: less than half a tap of
+        // the CU's requests) instead of asking the L2 again.  Nothing is exchanged at the barrier; every wave of a
+        // workgroup walks all K taps, so all of them arrive.
+#ifndef MFL_NO_TAP_BARRIER
+        __builtin_amdgcn_s_barrier();
+#endif
         load_weights(wn, pos + 1);
 #ifdef MFL_ABL_NO_RECORDS
         ConstWords rec1 = recp;
@@ -261,13 +281,14 @@ struct Loop {
         Offsets<CH> off2;
 #pragma unroll
         for (int j = 0; j < (CH + 1) / 2; ++j) thr1.w[j] = rec1[2 * CH + j];
+        thr1.next = rec1[2 * CH + (CH + 1) / 2];
         {
             ConstWords rec2 = pos + 2 <= K ? rec1 + rec_stride : rec1;
 #pragma unroll
             for (int c = 0; c < CH; ++c) { off2.a[c] = rec2[c]; off2.b[c] = rec2[CH + c]; }
         }
         MFL_SEG(0);
-        steps<SA, 0>(w);
+        steps<SA, 0, NEXT_B>(w);
         MFL_SEG(1);
         recp = rec1;
         thr = thr1;
@@ -287,7 +308,13 @@ struct Loop {
         // second copy of all accumulators across the inner loop, which doubled the kernel's register count)
         int ncols = 0;
         while (col + ncols < KS && (int)((cols_sa >> (4 * (col + ncols))) & 15) == SA) ++ncols;
-        for (int i = ncols * KS; i > 0; --i) tap<SA>(w);
+        if constexpr (SA == 0) {
+            // taps followed by another tap of class 0 request no side B; the last one requests it for the next class
+            for (int i = ncols * KS - 1; i > 0; --i) tap<0, false>(w);
+            if (ncols > 0) tap<0, true>(w);
+        } else {
+            for (int i = ncols * KS; i > 0; --i) tap<SA>(w);
+        }
         if constexpr (SA + 1 < KS) classes<SA + 1>(col + ncols, w);
     }
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copies the summaries of gpurun_out/r02 (tools/profile_round2.sh) into profiles/: kernel_stats csv per trace,
+"""Copies the summaries of gpurun_out/r02 (tools/profile_all.sh) into profiles/: kernel_stats csv per trace,
 one text file of mean counter values per dispatch for the kernels of interest per counter run, and
 profiles/traffic.json (memory-side bytes per launch of the fused step kernels)."""
 import csv, glob, json, os, shutil, sys
@@ -31,13 +31,13 @@ def counters(tag, patterns):
     return acc
 
 
-KERNELS = {"c4": ["ring_kernel", "weights_kernel"], "c2": ["diag_kernel"], "c5": ["local_forward_kernel", "label_step_kernel"],
+KERNELS = {"c4": ["ring_kernel", "weights_kernel"], "c2": ["diag_kernel"], "c5": ["diag_kernel", "label_step_kernel"],
            "ops": ["diag_kernel", "diag_backward_finish", "diag_backward_absmax"]}
 traffic = {}
 for tag, pats in KERNELS.items():
     acc = counters(tag, pats)
     with open(os.path.join(DST, f"r02_pmc_{tag}.txt"), "w") as out:
-        out.write(f"rocprofv3 --pmc passes of tools/profile_round2.sh ({tag}); mean counter value per dispatch\n")
+        out.write(f"rocprofv3 --pmc passes of tools/profile_all.sh ({tag}); mean counter value per dispatch\n")
         for p in pats:
             out.write(f"\n== kernels matching '{p}'\n")
             for name in sorted(acc[p]):

@@ -1,8 +1,8 @@
 #!/bin/bash
-# On the GPU box: the round's profiles.  Kernel traces of the bench per configuration, counter passes of the
+# On the GPU box: the profiles.  Kernel traces of the bench per configuration, counter passes of the
 # headline configuration (19 labels, 1024x2048, 11x11) and of the 21-label 512x512 configuration, counters of
 # the single operators (backward), and the FETCH_SIZE calibration.  Every rocprofv3 run is a run of its own.
-# Usage (repository root on the box): bash tools/profile_round2.sh
+# Usage (repository root on the box): bash tools/profile_all.sh
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
