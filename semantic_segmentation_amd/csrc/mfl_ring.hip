@@ -221,6 +221,9 @@ struct Loop {
     template <int SA, int STEP, bool NEXT_B>
     __device__ __forceinline__ void steps(const Weights<KS> &w)
     {
+#ifdef MFL_MID_BARRIER
+        if constexpr (STEP > 0 && STEP % MFL_MID_BARRIER == 0) __builtin_amdgcn_s_barrier();   // timing experiment
+#endif
         step<SA, STEP>(w);
 #ifndef MFL_ABL_NO_GLOADS
         // the next tap's elements into the registers this step has just consumed; the lanes past BL own no
@@ -465,7 +468,7 @@ weights_kernel(RingGeom rg, const F4 *__restrict__ ip4, const float *__restrict_
             // from the writes of the tap after it)
             for (int i = tid; i < WG * WQ * 64; i += NT) {
                 const int ol = i & 63, q = (i >> 6) % WQ, gg = i / (64 * WQ);
-                if (gq * WG + gg >= g.NG) continue;
+                if (gq * WG + gg >= g.NG || ol >= g.BL) continue;     // (lanes past BL own no pixels: never read)
                 const float *src = wt + gg * GST + ol * WP + 4 * q;
                 f4 v;
 #pragma unroll
@@ -511,7 +514,25 @@ ring_kernel(RingGeom rg, int lds_floats, int tail_per_group, const float *__rest
     const int rblk = blockIdx.x - img * per_image;
     const int tile = (rblk & 7) * (per_image >> 3) + (rblk >> 3);
     if (tile >= g.NBB * g.NGB) return;                // (the padding of the last eighth)
-    const int gb = tile % g.NGB, beta = tile / g.NGB;        // (b-block fastest instead: measured 3 % slower at 1024 x 2048, 11 x 11)
+    // Tile order within an image: b-blocks in patches of kPatch, the group blocks of a patch in turn, its b-blocks
+    // fastest.  Workgroups dispatched one after the other run a few taps apart, so their common cache lines meet in
+    // the XCD's L2: neighbouring group blocks overlap in whole element runs, neighbouring b-blocks in the line their
+    // runs straddle (b-blocks slowest: 4 % slower at 1024 x 2048, 11 x 11; b-blocks fastest: 2 % slower still).
+    constexpr int kPatch = 2;
+    int gb, beta;
+    {
+        const int full = (g.NBB / kPatch) * kPatch;            // b-blocks in complete patches
+        const int per_patch = kPatch * g.NGB;
+        if (tile < (full / kPatch) * per_patch) {
+            const int patch = tile / per_patch, r = tile - patch * per_patch;
+            gb = r / kPatch;
+            beta = patch * kPatch + r % kPatch;
+        } else {
+            const int r = tile - (full / kPatch) * per_patch, rest = g.NBB - full;
+            gb = r / rest;
+            beta = full + r % rest;
+        }
+    }
     const int gamma = gb * NGW + gi;
     const bool live = gamma < g.NG;
     const int C = g.C, CK = g.CK, L = g.L, W = g.W, Wp = g.Wp;
