@@ -43,6 +43,10 @@ using namespace mfl;
 #define MFL_NT_ST 0
 #endif
 
+// pixels per thread and epilogue chunk
+#ifndef MFL_EPI_MULT
+#define MFL_EPI_MULT 1
+#endif
 // waves per SIMD the fused step kernel is compiled for
 #ifndef MFL_M0_WAVES
 #define MFL_M0_WAVES 2
@@ -73,6 +77,7 @@ struct RingCfg {
     static constexpr int WQ = (KS + 3) / 4;                       // 16-byte pieces of a lane's k weights
     static constexpr int RECW = ((2 * CH + (CH + 1) / 2 + 1 + 3) / 4) * 4;
     static constexpr int CE = CH * NCS;
+    static constexpr int CBR = (NT / RUN) * MFL_EPI_MULT;         // b rows per epilogue chunk: MFL_EPI_MULT pixels per thread
 };
 
 // MFL_ABL_* macros: timing experiments only; they remove one part of the kernel and give wrong results.
@@ -566,7 +571,7 @@ ring_kernel(RingGeom rg, int lds_floats, int tail_per_group, const float *__rest
     __syncthreads();
 
     // ---- epilogue: accumulators -> LDS [channel][b_rel][a_rel], then one pixel per thread ----
-    constexpr int CBR = Cfg::NT / Cfg::RUN;          // b rows per chunk: one pixel per thread
+    constexpr int CBR = Cfg::CBR;                    // b rows per chunk
     static_assert(CBR >= 1, "a workgroup's threads cover at least one b row of its tile");
     const int cstride = CBR * Cfg::RUNP;
     // pixel r of the chunk starting at b row cb0: LDS place, output pixel l and centre position in
@@ -785,7 +790,7 @@ size_t lds_bytes_cfg(const RingGeom &r)
     const DiagGeom &g = r.d;
     size_t need = 0;
     // the epilogue tile: as many b rows of all channels as give every thread one pixel per chunk
-    const size_t epi = (size_t)Cfg::CE * Cfg::RUNP * (Cfg::NT / Cfg::RUN) * 4;
+    const size_t epi = (size_t)Cfg::CE * Cfg::RUNP * Cfg::CBR * 4;
     if (epi > need) need = epi;
     const size_t tail = ((size_t)g.CK + (size_t)Cfg::NW * kTailPix * (g.K + 2 * g.C)) * 4;
     if (g.tail_lanes && tail > need) need = tail;
@@ -805,7 +810,11 @@ int launch_cfg(const RingArgs &a, int mode, hipStream_t st)
     // regular tiles, then the workgroups of the tail pixels (one wave per chunk of kTailPix pixels)
     const int tail_per_group = g.tail_lanes ? diag_tail_per_group(g) : 0;
     const long long tail_waves = (long long)g.B * g.NG * ((tail_per_group + kTailPix - 1) / kTailPix);
+#ifdef MFL_ABL_NO_TAIL
+    const long long tail_blocks = 0;                  // timing experiment: the tail pixels are not computed
+#else
     const long long tail_blocks = (tail_waves + Cfg::NW - 1) / Cfg::NW;
+#endif
     const long long blocks = (long long)ring_blocks_per_image(g) * g.B + tail_blocks;
     if (blocks >= (1LL << 31)) return MFL_ERR_TOO_LARGE;
     const size_t lds = lds_bytes_cfg<CH, KS, NGW, NCS>(a.r);
