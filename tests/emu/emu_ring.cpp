@@ -4,8 +4,9 @@
 // "record offset + lane" (the shared element of a side) and, where the record's threshold says so, takes
 // instead the shared element of lane + gap of the same 64-lane load (the device's lane permute).  Checks
 // without a GPU: every pixel is produced exactly once (regular tiles plus the tail pixels of a nearly empty
-// last b-block), the side split per alignment class, the thresholds, and that the 65 - k owning lanes never
-// need an element past the 64 loaded ones.
+// last b-block), the side split per alignment class, the thresholds, that the 65 - k owning lanes never
+// need an element past the 64 loaded ones, and that an element of a lane past BL is only ever needed in a step
+// the previous record's flag word announces (those lanes request nothing otherwise).
 #include <stdlib.h>
 #include <string.h>
 
@@ -48,7 +49,7 @@ extern "C" int emu_ring_local_forward(const float *x, const float *img, float pw
     memset(y, 0, sizeof(float) * (size_t)B * C * g.L);
     memset(count, 0, sizeof(int) * (size_t)B * g.L);
     const size_t Lz = (size_t)g.L;
-    std::vector<uint32_t> rec(g.RECW);
+    std::vector<uint32_t> rec(g.RECW), prev(g.RECW);
     std::vector<float> acc((size_t)C * k);
     for (int b = 0; b < B; ++b) {
         const float *base = buf.data() + (size_t)b * per_image;   // FS floats before image b's planes
@@ -68,10 +69,18 @@ extern "C" int emu_ring_local_forward(const float *x, const float *img, float pw
                         const int sa = diag_align(g, kx), na = k - sa;
                         for (int ci = 0; ci < g.NCS; ++ci) {
                             ring_fill_record(r, beta, gamma, i, ci, rec.data());
+                            // which lanes past BL loaded along for this position: all of them at position 0 (the
+                            // loads before the loop), otherwise what the previous record's flag word says
+                            uint32_t wide = ~0u;
+                            if (i > 0) {
+                                ring_fill_record(r, beta, gamma, i - 1, ci, prev.data());
+                                wide = prev[2 * g.CH + (g.CH + 1) / 2];
+                            }
                             for (int s = 0; s < g.CH; ++s) {
                                 const int c = ci * g.CH + s;
                                 if (c >= C) continue;
                                 const uint32_t t16 = (rec[2 * g.CH + s / 2] >> (16 * (s & 1))) & 0xffffu;
+                                if ((t16 != 0x8080u) != (((wide >> s) & 1u) != 0) && i > 0) return -25;   // flag word out of step
                                 const int tA = (int)(t16 & 255u) - 64, tB = (int)(t16 >> 8) - 64;
                                 for (int n = 0; n < k; ++n) {
                                     const bool useA = n < na;
@@ -80,6 +89,7 @@ extern "C" int emu_ring_local_forward(const float *x, const float *img, float pw
                                     int src_lane = lane;
                                     if (t16 != 0x8080u && lane - T >= n) src_lane = lane + g.gap;   // the lane permute
                                     if (src_lane > 63) return -23;          // would wrap: only 65 - k lanes may own pixels
+                                    if (src_lane >= g.BL && !((wide >> s) & 1u)) return -24;   // that lane requested nothing
                                     acc[(size_t)c * k + n] += 0.f;          // (weights applied below, per pixel)
                                     // tap weight of pixel n
                                     const long long bb = (long long)g.BL * beta + lane - n;
