@@ -32,9 +32,11 @@
 
 using namespace mfl;
 
-// cache policy of the streamed operands (weight table, unary, outputs): 2 = non-temporal
+// cache policy of the streamed operands (weight table, unary, outputs): 2 = non-temporal.  Measured at 1024 x 2048,
+// 11 x 11 (ms per step on 8 images): weight table 5.94 against 6.03 (the second reader of a weight line still finds it
+// in L1, and the table, read once per step, displaces fewer element lines from the L2); unary 6.13; outputs 6.28
 #ifndef MFL_NT_W
-#define MFL_NT_W 0
+#define MFL_NT_W 2
 #endif
 #ifndef MFL_NT_U
 #define MFL_NT_U 0
@@ -695,7 +697,8 @@ ring_kernel(RingGeom rg, int lds_floats, int tail_per_group, const float *__rest
 #pragma unroll
                 for (int j = 0; j < KJ; ++j) m[j] = bload(rq, vq + (uint32_t)(2 * j * plane4));
 #pragma unroll
-                for (int v = 0; v < NV; ++v) u[v] = bload(ru, vu + (uint32_t)((8 * (v / 4) + (v % 4)) * L4));
+                for (int v = 0; v < NV; ++v)
+                    u[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ru, (int)(vu + (uint32_t)((8 * (v / 4) + (v % 4)) * L4)), 0, MFL_NT_U));
                 {
                     const float *msg = lds + moff;
 #pragma unroll
@@ -753,7 +756,7 @@ ring_kernel(RingGeom rg, int lds_floats, int tail_per_group, const float *__rest
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, __expf(u[v]) * rsv), rqo,
-                                                          (int)(sq + (uint32_t)((8 * (v / 4) + (v % 4)) * plane4)), 0, 0);
+                                                          (int)(sq + (uint32_t)((8 * (v / 4) + (v % 4)) * plane4)), 0, MFL_NT_ST);
                 if (logq) {
                     const float lsv = __logf(sv);
                     const uint32_t sl = ok ? vu : oob;
