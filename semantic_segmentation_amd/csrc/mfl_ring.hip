@@ -483,7 +483,8 @@ weights_kernel(RingGeom rg, const F4 *__restrict__ ip4, const float *__restrict_
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) v[jj] = 4 * q + jj < KS ? src[jj] : 0.f;
                 float *out = wtab + (unit0 + gg) * (size_t)K * (WQ * 256);
-                *reinterpret_cast<f4 *>(out + ((size_t)(pos * WQ + q) * 64 + ol) * 4) = v;
+                // (written once, read an iteration later and far larger than any cache: non-temporal)
+                __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(out + ((size_t)(pos * WQ + q) * 64 + ol) * 4));
             }
         }
     }
