@@ -43,107 +43,146 @@ __global__ void loop_exp_kernel(const float *__restrict__ logq, float *__restric
         q[i] = __expf(logq[i]);
 }
 
+typedef const float __attribute__((address_space(4))) *ConstFloats;   // scalar loads: never written while a kernel reads it
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+// ct32[j][i] = compat[i][j], zero-padded to 32 x 32: row j holds what dA_j = sum_i compat[i][j] * dP_i needs,
+// 128 contiguous bytes that the pre kernel reads with scalar loads.
+__global__ void loop_pad_compat_kernel(const float *__restrict__ compat, float *__restrict__ ct32, int C)
+{
+    const int j = threadIdx.x >> 5, i = threadIdx.x & 31;
+    ct32[threadIdx.x] = (i < C && j < C) ? compat[i * C + j] : 0.f;
+}
+
 // One workgroup (one wave) per 64 consecutive pixels of the image plane, looping over the batch so that
-// the sums over images (daw, dab) and over the pixels of the tile (dcompat) have a fixed order.
+// the sums over images (daw, dab) and over the pixels of the tile (dcompat) have a fixed order.  A lane owns one
+// pixel and keeps its channel vectors in registers (CE = label count rounded up to 8; channels past C hold zeros):
+// the label product dA = compat^T . dP takes the matrix rows from scalar registers, and the tile's share of
+// dcompat = sum_px dP (x) A runs on the matrix cores: 32 steps of v_mfma_f32_32x32x2_f32 (fp32 in and out) over the
+// tile's 64 pixels, rows = dP channels, columns = A channels, accumulated over the images in the same registers.
 //   g_in:    t = K-1: dL/dlogQ_K of the caller;  else dQ_{t+1} of the last local backward (from_dq)
 //   logq1:   logQ_{t+1}
 //   m:       M_t (local forward of Q_t), or NULL: then M_t = Q_t * (pos_w * P + col_w * Q) from the plain window
 //            sums P, Q of the local backward's first phase (xq = Q_t)
+//   ct32:    the padded transposed label matrix (MAT)
 //   dm:      out, gradient of M_t
 //   dls:     running sum of dz (first: overwritten)
-//   daw/dab: running sums (first: overwritten), [C][L]; NULL without the affine
-//   part:    out, this workgroup's C x C partial of dcompat (NULL without the matrix)
+//   daw/dab: running sums (first: overwritten), [C][L] (AFF)
+//   part:    out, this workgroup's C x C partial of dcompat (MAT)
+template <int CE, bool AFF, bool MAT>
 __global__ void __launch_bounds__(kPix)
 loop_pre_kernel(const float *__restrict__ g_in, int from_dq, const float *__restrict__ logq1, const float *__restrict__ m,
                 const float *__restrict__ xq, const float *__restrict__ psum, const float *__restrict__ qsum,
-                const float *__restrict__ pos_w, const float *__restrict__ col_w, const float *__restrict__ aw, const float *__restrict__ ab, const float *__restrict__ compat,
-                float *__restrict__ dm, float *__restrict__ dls, float *__restrict__ daw, float *__restrict__ dab,
-                float *__restrict__ part, int first, int B, int C, int L)
+                const float *__restrict__ pos_w, const float *__restrict__ col_w, const float *__restrict__ aw, const float *__restrict__ ab,
+                const float *__restrict__ ct32, float *__restrict__ dm, float *__restrict__ dls, float *__restrict__ daw,
+                float *__restrict__ dab, float *__restrict__ part, int first, int B, int C, int L)
 {
     extern __shared__ float lds[];
-    float *dp = lds;                       // [C][kPitch]  dP of the current image
-    float *at = dp + C * kPitch;           // [C][kPitch]  A_t of the current image
-    float *sw = at + C * kPitch;           // [C][kPitch]  sum_b dA * M
-    float *sb = sw + C * kPitch;           // [C][kPitch]  sum_b dA
-    float *cacc = sb + C * kPitch;         // [C*C]        sum dP (x) A
-    float *cm = cacc + C * C;              // [C*C]        the label matrix (read once per workgroup)
+    float *dp = lds;                       // [32][kPitch]  dP of the current image (MAT)
+    float *at = dp + 32 * kPitch;          // [32][kPitch]  A_t of the current image (MAT)
     const int lane = threadIdx.x;
-    const int l = blockIdx.x * kPix + lane;
-    const bool ok = l < L;
+    const int l0 = blockIdx.x * kPix + lane;
+    const bool ok = l0 < L;
+    const int l = ok ? l0 : L - 1;         // (lanes past the plane load the last pixel and keep zeros)
     const float pw = m ? 0.f : *pos_w, cw = m ? 0.f : *col_w;
-    auto message = [&](size_t o) { return m ? m[o] : xq[o] * fmaf(pw, psum[o], cw * qsum[o]); };
-    for (int c = 0; c < C; ++c) { sw[c * kPitch + lane] = 0.f; sb[c * kPitch + lane] = 0.f; }
-    for (int i = lane; i < C * C; i += kPix) {
-        cacc[i] = 0.f;
-        cm[i] = compat ? compat[i] : 0.f;
+    if constexpr (MAT) {
+        for (int i = lane; i < 2 * 32 * kPitch; i += kPix) lds[i] = 0.f;     // rows of the channels past CE stay zero
+        __syncthreads();
     }
-    __syncthreads();
+    float sw[CE], sb[CE];
+#pragma unroll
+    for (int c = 0; c < CE; ++c) { sw[c] = 0.f; sb[c] = 0.f; }
+    f16v dacc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) dacc[v] = 0.f;
+    const int p = lane & 31, h = lane >> 5;
     for (int b = 0; b < B; ++b) {
         const size_t base = (size_t)b * C * L + l;
+        // (everything of a pixel stays in registers and all loads of an image are requested at once: measured faster
+        // than parking the affine values in LDS or bounding the loads in flight, which allow more waves per SIMD)
+        float g[CE], q[CE], a[CE], mv[CE];
         float sg = 0.f;
-        for (int c = 0; c < C; ++c) {
-            float g = 0.f, q = 0.f, a = 0.f;
-            if (ok) {
-                q = __expf(logq1[base + (size_t)c * L]);
-                g = g_in[base + (size_t)c * L];
-                if (from_dq) g *= q;
-                const float mv = message(base + (size_t)c * L);
-                a = aw ? fmaf(aw[(size_t)c * L + l], mv, ab[(size_t)c * L + l]) : mv;
+#pragma unroll
+        for (int c = 0; c < CE; ++c) {
+            const size_t o = base + (size_t)(c < C ? c : C - 1) * L;
+            const bool live = ok && c < C;
+            q[c] = __expf(logq1[o]);
+            float gv = g_in[o];
+            if (from_dq) gv *= q[c];
+            g[c] = live ? gv : 0.f;
+            mv[c] = m ? m[o] : xq[o] * fmaf(pw, psum[o], cw * qsum[o]);
+            float av = mv[c];
+            if constexpr (AFF) {
+                const size_t oc = (size_t)(c < C ? c : C - 1) * L + l;
+                av = fmaf(aw[oc], av, ab[oc]);
             }
-            dp[c * kPitch + lane] = g;      // g for now
-            at[c * kPitch + lane] = a;
-            sg += g;
+            a[c] = live ? av : 0.f;
+            sg += g[c];
         }
-        for (int c = 0; c < C; ++c) {
-            float dz = 0.f;
-            if (ok) {
-                const float q = __expf(logq1[base + (size_t)c * L]);
-                dz = dp[c * kPitch + lane] - q * sg;
-                dls[base + (size_t)c * L] = first ? dz : dls[base + (size_t)c * L] + dz;
+        // dz = g - Q * sum g;  dP = -dz (kept in g)
+#pragma unroll
+        for (int c = 0; c < CE; ++c) {
+            const float dz = g[c] - q[c] * sg;
+            if (ok && c < C) {
+                const size_t o = base + (size_t)c * L;
+                dls[o] = first ? dz : dls[o] + dz;
             }
-            dp[c * kPitch + lane] = -dz;
+            g[c] = (ok && c < C) ? -dz : 0.f;
         }
-        __syncthreads();
-        // dA_j = sum_i compat[i][j] * dP_i (this thread's pixel); dM_j = aw_j * dA_j
-        for (int j = 0; j < C; ++j) {
+        // dA_j = sum_i compat[i][j] * dP_i;  dM_j = aw_j * dA_j
+#pragma unroll
+        for (int j = 0; j < CE; ++j) {
             float da;
-            if (compat) {
+            if constexpr (MAT) {
+                ConstFloats row = (ConstFloats)(uintptr_t)(ct32 + j * 32);
                 da = 0.f;
-                for (int i = 0; i < C; ++i) da = fmaf(cm[i * C + j], dp[i * kPitch + lane], da);
+#pragma unroll
+                for (int i = 0; i < CE; ++i) da = fmaf(row[i], g[i], da);
             } else {
-                da = dp[j * kPitch + lane];
+                da = g[j];
             }
-            if (ok) {
-                float dmv = da;
-                if (aw) {
-                    const float mv = message(base + (size_t)j * L);
-                    sw[j * kPitch + lane] = fmaf(da, mv, sw[j * kPitch + lane]);
-                    sb[j * kPitch + lane] += da;
-                    dmv = aw[(size_t)j * L + l] * da;
+            float dmv = da;
+            if constexpr (AFF) {
+                sw[j] = fmaf(da, mv[j], sw[j]);
+                sb[j] += da;
+                dmv = aw[(size_t)(j < C ? j : C - 1) * L + l] * da;
+            }
+            if (ok && j < C) dm[base + (size_t)j * L] = dmv;
+        }
+        if constexpr (MAT) {
+            // the tile's dP and A through LDS, then D[i][j] += sum_px dP_i(px) * A_j(px): lane (p, h) feeds row / column p
+            // of pixel 2 s + h at step s and holds D[8 (v / 4) + 4 h + v % 4][p] in register v
+#pragma unroll
+            for (int c = 0; c < CE; ++c) {
+                dp[c * kPitch + lane] = g[c];
+                at[c * kPitch + lane] = a[c];
+            }
+            __syncthreads();
+#pragma unroll 8
+            for (int s = 0; s < kPix / 2; ++s)
+                dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dp[p * kPitch + 2 * s + h], at[p * kPitch + 2 * s + h], dacc, 0, 0, 0);
+            __syncthreads();
+        }
+    }
+    if constexpr (AFF) {
+        if (ok) {
+#pragma unroll
+            for (int c = 0; c < CE; ++c) {
+                if (c < C) {
+                    const size_t o = (size_t)c * L + l;
+                    daw[o] = first ? sw[c] : daw[o] + sw[c];
+                    dab[o] = first ? sb[c] : dab[o] + sb[c];
                 }
-                dm[base + (size_t)j * L] = dmv;
             }
         }
-        if (part) {
-            // pair (i, j) of the matrix: sum over the tile's pixels (rows of pixels past L hold zeros)
-            for (int idx = lane; idx < C * C; idx += kPix) {
-                const int i = idx / C, j = idx - i * C;
-                float s = 0.f;
-                for (int px = 0; px < kPix; ++px) s = fmaf(dp[i * kPitch + px], at[j * kPitch + px], s);
-                cacc[idx] += s;
-            }
-        }
-        __syncthreads();
     }
-    if (ok && daw) {
-        for (int c = 0; c < C; ++c) {
-            const size_t o = (size_t)c * L + l;
-            daw[o] = first ? sw[c * kPitch + lane] : daw[o] + sw[c * kPitch + lane];
-            dab[o] = first ? sb[c * kPitch + lane] : dab[o] + sb[c * kPitch + lane];
+    if constexpr (MAT) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int i = 8 * (v / 4) + 4 * h + (v % 4);
+            if (i < C && p < C) part[(size_t)blockIdx.x * C * C + i * C + p] = dacc[v];
         }
     }
-    if (part)
-        for (int i = lane; i < C * C; i += kPix) part[(size_t)blockIdx.x * C * C + i] = cacc[i];
 }
 
 // dcompat[i][j] (+)= sum over the workgroups' partials: one workgroup per matrix element, every thread sums a
@@ -194,7 +233,7 @@ __global__ void loop_final_kernel(const float *__restrict__ unary, const float *
 }
 
 struct LoopWorkspace {
-    size_t logq_all, x, m, dm, dx, dls, dpar, part, sub, sub_bytes, total;
+    size_t logq_all, x, m, dm, dx, dls, dpar, part, ct32, sub, sub_bytes, total;
     int nblk;
 };
 
@@ -214,6 +253,7 @@ LoopWorkspace loop_carve(int B, int C, int H, int W, int k, int iters)
     w.dpar = take((size_t)iters * 2 * 4);
     w.nblk = (L + kPix - 1) / kPix;
     w.part = take((size_t)w.nblk * C * C * 4);
+    w.ct32 = take(32 * 32 * 4);
     size_t sub = mfl_workspace_bytes(MFL_OP_MEANFIELD_FORWARD, B, C, H, W, k, iters);
     const size_t f = mfl_workspace_bytes(MFL_OP_LOCAL_FORWARD, B, C, H, W, k, 1);
     const size_t bw = mfl_workspace_bytes(MFL_OP_LOCAL_BACKWARD, B, C, H, W, k, 1);
@@ -264,7 +304,7 @@ extern "C" int mfl_meanfield_backward(const float *unary, const float *img, cons
     if ((affine_w != nullptr) != (d_affine_w != nullptr) || (affine_w != nullptr) != (d_affine_b != nullptr))
         return MFL_ERR_INVALID_ARGUMENT;
     if ((compat != nullptr) != (d_compat != nullptr)) return MFL_ERR_INVALID_ARGUMENT;
-    if (C > kMaxC) return MFL_ERR_INVALID_ARGUMENT;           // the pre kernel holds four C x 65 tiles and C x C sums in LDS
+    if (C > kMaxC) return MFL_ERR_INVALID_ARGUMENT;           // the pre kernel holds a pixel's channel vectors in registers
     if ((long long)B * C * H * W >= (1LL << 31)) return MFL_ERR_TOO_LARGE;
     const size_t need = mfl::loop_backward_workspace_bytes(B, C, H, W, k, iters);
     if (need == 0) return MFL_ERR_INVALID_ARGUMENT;
@@ -274,7 +314,7 @@ extern "C" int mfl_meanfield_backward(const float *unary, const float *img, cons
     const float *logq_all = logq_iterates ? logq_iterates : (const float *)(base + ws.logq_all);
     float *x = (float *)(base + ws.x), *m = (float *)(base + ws.m);
     float *dm = (float *)(base + ws.dm), *dx = (float *)(base + ws.dx), *dls = (float *)(base + ws.dls);
-    float *dpar = (float *)(base + ws.dpar), *part = (float *)(base + ws.part);
+    float *dpar = (float *)(base + ws.dpar), *part = (float *)(base + ws.part), *ct32 = (float *)(base + ws.ct32);
     void *sub = base + ws.sub;
     hipStream_t st = (hipStream_t)stream;
     const int L = H * W;
@@ -287,7 +327,24 @@ extern "C" int mfl_meanfield_backward(const float *unary, const float *img, cons
                                          W, k, iters, sub, ws.sub_bytes, stream);
         if (rc) return rc;
     }
-    const size_t lds = ((size_t)4 * C * kPitch + (size_t)2 * C * C) * 4;
+    const size_t lds = compat ? (size_t)2 * 32 * kPitch * 4 : 0;
+    if (compat) hipLaunchKernelGGL(loop_pad_compat_kernel, dim3(1), dim3(1024), 0, st, compat, ct32, C);
+    // the pre kernel of this call: channel capacity (C rounded up to 8) x affine x label matrix
+    using PreKernel = void (*)(const float *, int, const float *, const float *, const float *, const float *, const float *,
+                               const float *, const float *, const float *, const float *, const float *, float *, float *, float *,
+                               float *, float *, int, int, int, int);
+    PreKernel pre = nullptr;
+    {
+        const bool aff = affine_w != nullptr, mat = compat != nullptr;
+#define MFL_PRE_PICK(CEV)                                                                     \
+        pre = aff ? (mat ? loop_pre_kernel<CEV, true, true> : loop_pre_kernel<CEV, true, false>) \
+                  : (mat ? loop_pre_kernel<CEV, false, true> : loop_pre_kernel<CEV, false, false>)
+        if (C <= 8) MFL_PRE_PICK(8);
+        else if (C <= 16) MFL_PRE_PICK(16);
+        else if (C <= 24) MFL_PRE_PICK(24);
+        else MFL_PRE_PICK(32);
+#undef MFL_PRE_PICK
+    }
     const bool split = mfl::local_backward_split_supported(B, C, H, W, k);
     const unsigned egrid = (unsigned)((n + 255) / 256 < 65535 * 8 ? (n + 255) / 256 : 65535 * 8);
     for (int t = iters - 1; t >= 0; --t) {
@@ -306,9 +363,9 @@ extern "C" int mfl_meanfield_backward(const float *unary, const float *img, cons
         }
         if (rc) return rc;
         const int first = t == iters - 1;
-        hipLaunchKernelGGL(loop_pre_kernel, dim3(ws.nblk), dim3(kPix), lds, st, first ? grad_logq : dx, first ? 0 : 1,
-                           logq_all + (size_t)t * n, split ? nullptr : m, xt, psum, qsum, pos_w, col_w, affine_w, affine_b, compat, dm,
-                           dls, d_affine_w, d_affine_b, compat ? part : nullptr, first, B, C, L);
+        hipLaunchKernelGGL(pre, dim3(ws.nblk), dim3(kPix), lds, st, first ? grad_logq : dx, first ? 0 : 1,
+                           logq_all + (size_t)t * n, split ? nullptr : m, xt, psum, qsum, pos_w, col_w, affine_w, affine_b,
+                           (const float *)ct32, dm, dls, d_affine_w, d_affine_b, compat ? part : nullptr, first, B, C, L);
         if (compat)
             hipLaunchKernelGGL(loop_compat_reduce_kernel, dim3(C * C), dim3(256), 0, st, part, ws.nblk, C * C, d_compat, first);
         MFL_CHECK_HIP(hipGetLastError());
