@@ -337,7 +337,7 @@ Workspace carve(int op, const Geom &g, int cc)
     }
     if (op == MFL_OP_MEANFIELD_FORWARD) {
         w.xp2 = take(padded_floats(g) * 4);
-        if (g.C > 32) w.msg = take((size_t)g.B * g.C * g.L * 4);
+        if (g.C > 32 || taps_kernel_applies(g)) w.msg = take((size_t)g.B * g.C * g.L * 4);
     }
     w.total = off;
     return w;
@@ -1218,7 +1218,12 @@ static int meanfield_forward_impl(const float *unary, const float *img, const fl
         }
         return MFL_OK;
     }
-    const bool fused = C <= 32;
+    // (large windows on small images: the tap-split forward kernel, then the unfused label step)
+    bool fused = C <= 32;
+    {
+        Geom g1;
+        if (fused && make_geom(g1, B, C, H, W, k, 1) == 0 && taps_kernel_applies(g1)) fused = false;
+    }
     // the label transform of the unfused path stages 64 pixels x C messages in LDS (160 KB per workgroup)
     if (!fused && (affine_w || compat) && (size_t)C * 64 * 4 > 160 * 1024) return MFL_ERR_INVALID_ARGUMENT;
     Geom g;

@@ -23,6 +23,17 @@ struct GatherArgs {
     const float *pos_w, *col_w;
 };
 
+// The shapes the tap-split forward kernel takes (local_forward_taps_kernel): a window of at least 16 x 16 taps and so
+// few pixels that one pixel per thread cannot fill the GPU (the reference model's own 64 x 64 image with a 50 x 50
+// window).  The mean-field loop then runs unfused on these shapes: window products, label transform, combine.
+inline bool taps_kernel_applies(const Geom &g)
+{
+#ifdef MFL_NO_TAPS_KERNEL
+    return false;       // comparison builds
+#endif
+    return g.K >= 256 && (long long)g.B * g.L <= 64 * 1024;
+}
+
 struct BackwardArgs {
     const float *dy;
     float *dxd, *dxp, *partials, *dcd;

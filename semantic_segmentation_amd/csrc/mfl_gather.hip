@@ -78,6 +78,98 @@ local_forward_kernel(Geom g, const float *__restrict__ xp, const F4 *__restrict_
     }
 }
 
+// Large windows on small images (the reference model's own 50 x 50 window on a 64 x 64 image, AdvancedModel.py:135-137):
+// with one pixel per thread a thread walks K dependent taps (a table entry, then the element it addresses), which is
+// bound by that latency, and the few pixels leave most CUs idle.  Here the taps of a pixel are split over kTapSlices
+// threads (kTapPixels pixels per workgroup); the partial sums meet in LDS and are added in a fixed order.
+// Same index walk as window_sums (mfl_core.h) with one pixel per thread, started at the slice's first tap.
+constexpr int kTapSlices = 16, kTapPixels = kThreads / kTapSlices;
+
+template <int CC>
+__global__ void __launch_bounds__(kThreads)
+local_forward_taps_kernel(Geom g, const float *__restrict__ xp, const F4 *__restrict__ ip4, const int *__restrict__ tab,
+                          const float *__restrict__ pos_w, const float *__restrict__ col_w, float *__restrict__ y)
+{
+    __shared__ float red[kTapSlices][CC][kTapPixels + 1];
+    const int tid = threadIdx.x, pxi = tid % kTapPixels, slice = tid / kTapPixels;
+    const int b = blockIdx.z, c0 = blockIdx.y * CC;
+    const int nch = min(CC, g.C - c0);
+    const int l_raw = blockIdx.x * kTapPixels + pxi;
+    const int l = l_raw < g.L ? l_raw : g.L - 1;
+    const int W = g.W, Wp = g.Wp, gap = Wp - W, CK = g.CK;
+    const int py = l / W, px = l - py * W;
+    const int ibase = py * Wp + px;
+    const float *xp_b = xp + (size_t)b * g.C * g.plane;
+    const F4 *ip_b = ip4 + (size_t)b * g.plane;
+    const float pw = *pos_w, cw = *col_w;
+    const int t0 = (int)((long long)g.K * slice / kTapSlices), t1 = (int)((long long)g.K * (slice + 1) / kTapSlices);
+    // decode state of (channel c0, tap t0): table index rs, source column xs, padded offset ls = y' * Wp + x'
+    const long long f0 = ((long long)c0 * g.K + t0) * g.L + l;
+    const long long lp0 = f0 / CK;
+    int rs = (int)(f0 - lp0 * CK);
+    int xs = (int)(lp0 % W);
+    int ls = (int)(lp0 / W) * Wp + xs;
+    const int dq_lin = g.dqy * Wp + g.dqx, dK_lin = g.dKy * Wp + g.dKx;
+    float acc[CC];
+#pragma unroll
+    for (int cc = 0; cc < CC; ++cc) acc[cc] = 0.f;
+    const F4 ctr = ip_b[ibase + g.p0 * Wp + g.p0];
+    int ky = t0 / g.k, kx = t0 - ky * g.k;
+    for (int t = t0; t < t1; ++t) {
+        const F4 nb = ip_b[ibase + ky * Wp + kx];
+        const float d0 = ctr.x - nb.x, d1 = ctr.y - nb.y, d2 = ctr.z - nb.z;
+        const int dy = ky - g.p0, dx = kx - g.p0;
+        const float w = fmaf(d0 * d0 + d1 * d1 + d2 * d2, cw, (float)(dy * dy + dx * dx) * pw);
+        int r = rs, x = xs, lin = ls;
+        int a[CC];
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc) {
+            a[cc] = lin + tab[r];
+            if (cc >= nch) a[cc] = a[0];          // channels past the chunk: a valid dummy
+            r += g.rhoK;
+            const int carry = r >= CK;
+            r -= carry ? CK : 0;
+            x += g.dKx + carry;
+            const int wrap = x >= W;
+            x -= wrap ? W : 0;
+            lin += dK_lin + carry + (wrap ? gap : 0);
+        }
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc) acc[cc] = fmaf(w, xp_b[a[cc]], acc[cc]);
+        // decode step to the next tap
+        rs += g.rho;
+        const int carry = rs >= CK;
+        rs -= carry ? CK : 0;
+        xs += g.dqx + carry;
+        const int wrap = xs >= W;
+        xs -= wrap ? W : 0;
+        ls += dq_lin + carry + (wrap ? gap : 0);
+        if (++kx == g.k) { kx = 0; ++ky; }
+    }
+#pragma unroll
+    for (int cc = 0; cc < CC; ++cc) red[slice][cc][pxi] = acc[cc];
+    __syncthreads();
+    if (l_raw < g.L) {
+        const int ctr_off = g.p0 * Wp + g.p0;
+        for (int cc = slice; cc < nch; cc += kTapSlices) {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < kTapSlices; ++i) sum += red[i][cc][pxi];
+            const int c = c0 + cc;
+            y[((size_t)b * g.C + c) * g.L + l] = sum * xp_b[(size_t)c * g.plane + ibase + ctr_off];
+        }
+    }
+}
+
+template <int CC>
+int launch_fwd_taps(const GatherArgs &a, float *y, hipStream_t st)
+{
+    const Geom &g = a.g;
+    const dim3 grid((g.L + kTapPixels - 1) / kTapPixels, (g.C + CC - 1) / CC, g.B);
+    hipLaunchKernelGGL((local_forward_taps_kernel<CC>), grid, dim3(kThreads), 0, st, g, a.xp, a.ip4, a.tab, a.pos_w, a.col_w, y);
+    return (int)hipGetLastError();
+}
+
 #endif  // MFL_KIND == 1
 
 #if MFL_KIND == 3
@@ -381,6 +473,7 @@ int MFL_CAT(launch_local_forward_cc, MFL_CC)(const GatherArgs &a, float *y, hipS
     constexpr int CC = MFL_CC;
     if (a.from_cd)   // caller-supplied tensor: compatibility path, one pixel per thread
         return a.tab_lds ? launch_fwd<CC, 1, true, true>(a, y, st) : launch_fwd<CC, 1, true, false>(a, y, st);
+    if (taps_kernel_applies(a.g)) return launch_fwd_taps<CC>(a, y, st);
     if (!a.tab_lds) return launch_fwd<CC, 1, false, false>(a, y, st);
     switch (a.g.M) {
     case 1: return launch_fwd<CC, 1, false, true>(a, y, st);
