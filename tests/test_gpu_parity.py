@@ -236,6 +236,27 @@ def strict_rel_err_on_marginals(logq, ref_logq):
     return float((np.abs(q - qr)[m] / qr[m]).max())
 
 
+@pytest.mark.parametrize("shape", [(1, 21, 64, 64, 50), (2, 5, 40, 48, 20), (1, 32, 64, 64, 17)])
+@pytest.mark.parametrize("mode", ["plain", "compat", "affine+compat"])
+def test_meanfield_large_window_vs_oracle(shape, mode, S, oracle):
+    """Large windows on small images (the reference model's own 64 x 64 / 50 x 50 configuration, AdvancedModel.py:135-137):
+    the tap-split forward kernel and the unfused label step.  Weights small enough that 2 500 taps keep the logits
+    in a range where the elementwise figure on the marginals means something."""
+    B, C, H, W, k = shape
+    unary, img, _ = make_inputs(shape, 5)
+    rng = np.random.default_rng(11)
+    compat = ((1 - np.eye(C)) + 0.01 * rng.standard_normal((C, C))).astype(np.float32) if "compat" in mode else None
+    aw = (1 + 0.2 * rng.standard_normal((1, C, H, W))).astype(np.float32) if "affine" in mode else None
+    ab = (0.1 * rng.standard_normal((1, C, H, W))).astype(np.float32) if "affine" in mode else None
+    opt = lambda a: None if a is None else dev(a)
+    pw, cw = -4e-5 * (49.0 / (k * k)), -3e-4 * (49.0 / (k * k))
+    for iters in (1, 2):
+        lq = host(S.ops.meanfield_forward(dev(unary), dev(img), scalar(pw), scalar(cw), k, iters, opt(aw), opt(ab), opt(compat)))
+        ref = oracle.meanfield_forward(unary, img, pw, cw, k, iters, aw, ab, compat)
+        assert_close(lq, ref, RTOL, f"logq {mode} iters={iters}")
+        assert strict_rel_err_on_marginals(lq, ref) < 1e-4
+
+
 @pytest.mark.parametrize("shape", [SHAPES[0], SHAPES[1], SHAPES[2], SHAPES[3], SHAPES[5]] + DIAG_SHAPES)
 @pytest.mark.parametrize("mode", ["plain", "compat", "affine+compat"])
 def test_meanfield_vs_oracle(shape, mode, S, oracle):
