@@ -166,7 +166,9 @@ int mfl_meanfield_forward_iterates(const float *unary, const float *img, const f
  *   d_affine_w, d_affine_b: [C][H][W], overwritten; non-NULL exactly when affine_w is
  *   d_compat:   [C][C], overwritten; non-NULL exactly when compat is
  * C <= 32.  All sums over images and pixels outside the local operator's own
- * backward have a fixed order.
+ * backward have a fixed order.  The address tables of the nested operator calls
+ * are rebuilt once per call (their plan tag lies inside this workspace and is
+ * cleared on entry), so the workspace may be any memory, whatever it held before.
  */
 int mfl_meanfield_backward(const float *unary, const float *img, const float *pos_w, const float *col_w,
                            const float *affine_w, const float *affine_b, const float *compat, const float *logq_iterates,
@@ -185,6 +187,9 @@ int mfl_meanfield_backward(const float *unary, const float *img, const float *po
  * with MFL_ERR_SCRATCH_LIMIT (64 MiB holds one 21-label 512x512 image with a
  * 7x7 window).  All calls on one GPU share that GPU's buffer: calls that overlap
  * in time on one GPU (different streams or threads) race; serialise them.  The
+ * buffer is part of the library's code object: every GPU the library runs on
+ * holds its MFL_NOALLOC_SCRATCH_BYTES while the library is loaded, whether this
+ * entry point is ever called or not.  The
  * first call on a device looks up the buffer's address (set-up; do it once
  * before capturing a graph).  Same arguments, results and return codes as
  * mfl_meanfield_forward otherwise.

@@ -526,6 +526,9 @@ __global__ void diag_backward_scale_kernel(const float *__restrict__ pos_w, cons
     e = e > 100 ? 100 : (e < -100 ? -100 : e);
     c[4] = ldexpf(1.f, e);
     c[5] = ldexpf(1.f, -e);
+    // a non-finite gradient, input or image (the maxima count NaN as the largest value) has no fixed-point scale:
+    // nothing is scattered (scale 0) and every dx comes out NaN, as the reference's autograd would propagate it
+    if (!(bound < INFINITY)) { c[4] = 0.f; c[5] = NAN; }
 }
 
 // dx = dy * (pos_w * P + col_w * Q) + scattered term (interior of the padded planes of fixed-point sums, consts[5] = 1 / scale);
@@ -1262,12 +1265,9 @@ static int meanfield_forward_impl(const float *unary, const float *img, const fl
                 continue;
             }
             if (affine_w || compat) {
-                static bool raised = false;     // more than the default 64 KB of dynamic LDS past 256 labels
-                if (!raised) {
-                    MFL_CHECK_HIP(hipFuncSetAttribute((const void *)label_transform_kernel,
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                    raised = true;
-                }
+                // more than the default 64 KB of dynamic LDS past 256 labels (per device: set before every launch)
+                MFL_CHECK_HIP(hipFuncSetAttribute((const void *)label_transform_kernel,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 hipLaunchKernelGGL(label_transform_kernel, dim3((unsigned)((npix + 63) / 64)), dim3(kThreads),
                                    (size_t)C * 64 * 4, st, msg, affine_w, affine_b, compat, msg, B, C, H, W);
             }

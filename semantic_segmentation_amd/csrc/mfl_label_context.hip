@@ -245,11 +245,8 @@ int launch(const ContextWorkspace &ws, char *base, const float *conv_b, const fl
     if (groups >= (1LL << 31)) return MFL_ERR_TOO_LARGE;
     const size_t lds = (size_t)kChunk * 32 * M * 4 + (size_t)ws.KKp * 4;
     if (lds > 160 * 1024) return MFL_ERR_INVALID_ARGUMENT;
-    static bool raised = false;       // (a property of the kernel: set once per process)
-    if (!raised) {
-        MFL_CHECK_HIP(hipFuncSetAttribute((const void *)label_context_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        raised = true;
-    }
+    // (the attribute belongs to the current device's copy of the kernel: set before every launch)
+    MFL_CHECK_HIP(hipFuncSetAttribute((const void *)label_context_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(label_context_kernel<M>, dim3((unsigned)groups), dim3(64 * kWavesPerGroup), lds, st,
                        (const float *)(base + ws.apad), (const float *)(base + ws.w2), (const int *)(base + ws.koff), conv_b, ga_w, ga_b,
                        unary, smooth, logq, B, L, H, W, ws.Wp, ws.Hp * ws.Wp, ws.KKp, tiles_per_row);

@@ -164,11 +164,10 @@ int launch(const float *msg, const float *aw, const float *ab, const float *comp
            int q_pad_k, int B, int C, int H, int W, hipStream_t st)
 {
     const size_t lds = (size_t)2 * ((C + 1) / 2) * 32 * MB * 4;
-    static bool raised = false;       // (the attribute is a property of the kernel: set once per process)
-    if (!raised) {
+    {
+        // (the attribute belongs to the current device's copy of the kernel: set before every launch)
         const hipError_t e = hipFuncSetAttribute((const void *)label_step_kernel<MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        raised = true;
     }
     const long long ntiles = ((long long)B * H * W + 31) / 32;
     long long blocks = (ntiles + kWaves - 1) / kWaves;

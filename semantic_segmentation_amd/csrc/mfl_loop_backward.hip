@@ -320,6 +320,12 @@ extern "C" int mfl_meanfield_backward(const float *unary, const float *img, cons
     const int L = H * W;
     const size_t n = (size_t)B * C * L;
 
+    // The nested operator calls keep their address tables in `sub` and skip rebuilding them when they find their own
+    // plan tag there.  That tag sits in the middle of this call's workspace, where no caller-side rule protects it
+    // (a block that went back to an allocator in between may come back with the tag intact and the tables
+    // overwritten), so it is not trusted across calls: cleared here, the tables are built once per call and reused
+    // by its K iterations.
+    MFL_CHECK_HIP(hipMemsetAsync(sub, 0, 256, st));
     int rc = 0;
     if (!logq_iterates) {
         // no iterates from the caller (mfl_meanfield_forward_iterates): the forward loop runs again and keeps them

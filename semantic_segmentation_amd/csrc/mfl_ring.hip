@@ -827,14 +827,10 @@ int launch_cfg(const RingArgs &a, int mode, hipStream_t st)
     if (lds > 160 * 1024) return MFL_ERR_INVALID_ARGUMENT;
     const dim3 grid((unsigned)blocks);
     auto go = [&](auto kern) -> int {
-        // the attribute is a property of the kernel: set once per process and kernel (racing first calls
-        // set the same value)
-        static bool raised = false;
-        if (!raised) {
-            const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return (int)e;
-            raised = true;
-        }
+        // the attribute belongs to the current device's copy of the kernel: set before every launch (a process may
+        // drive several devices; the call is cheap)
+        const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), lds, st, a.r, (int)(lds / 4), tail_per_group, a.xp, a.ip4, a.table, a.wtab, a.pos_w,
                            a.col_w, a.unary, a.aw, a.ab, a.compat, a.compat_plain, a.logq, a.qp_out, a.y);
         return 0;

@@ -262,6 +262,178 @@ def gen_meanfield_grad(LC, AM):
         save("mfgrad_" + os.path.basename(path)[len("meanfield_"):-len(".npz")], **out)
 
 
+def _metrics_stub(AM, num_labels):
+    """An object with just what DPNModel's metric helpers read from `self` (AdvancedModel.py:427-517); building a
+    whole DPNModel (139 M parameters) for them would add nothing."""
+    stub = types.SimpleNamespace(num_labels=num_labels, image_size=None)
+    stub.calc_intersection_over_union = lambda *a, **k: AM.DPNModel.calc_intersection_over_union(stub, *a, **k)
+    return stub
+
+
+def gen_metrics(AM):
+    """DPNModel.calc_intersection_over_union / calc_mean_intersection_over_union (AdvancedModel.py:427-485) and
+    DPNModel._calc_weights (AdvancedModel.py:500-517) on seeded label maps (tensors / arrays: the PIL branches only
+    resize)."""
+    rng = np.random.default_rng(707)
+    C = 21
+    out = {"num_labels": np.int64(C)}
+    for ci, (shape, present) in enumerate([((3, 96, 130), 19), ((1, 40, 40), 21), ((2, 17, 23), 5)]):
+        target = rng.integers(0, present, size=shape).astype(np.uint8)       # classes >= present never appear
+        target[rng.random(shape) < 0.05] = 255                               # void
+        pred = np.where(rng.random(shape) < 0.7, target, rng.integers(0, present, size=shape)).astype(np.uint8)
+        pred[pred == 255] = 3
+        stub = _metrics_stub(AM, C)
+        out[f"pred{ci}"], out[f"target{ci}"] = pred, target
+        for bg in (False, True):
+            iou = AM.DPNModel.calc_intersection_over_union(stub, torch.from_numpy(pred.astype(np.int64)),
+                                                           torch.from_numpy(target.astype(np.int64)), bg)
+            mean = AM.DPNModel.calc_mean_intersection_over_union(stub, torch.from_numpy(pred.astype(np.int64)),
+                                                                 torch.from_numpy(target.astype(np.int64)), bg)
+            out[f"iou{ci}_bg{int(bg)}"] = npy(iou)
+            out[f"miou{ci}_bg{int(bg)}"] = np.float64(mean)
+        # the reference takes a list of annotated images; np.array(image) is all it does with each
+        out[f"weights{ci}"] = npy(AM.DPNModel._calc_weights(stub, [target[b] for b in range(shape[0])]))
+    save("metrics_l21", **out)
+
+
+def gen_tail_grad(AM):
+    """Autograd gradients through the label-context tail a5 -> a8 -> a6 -> a7 (AdvancedModel.py:223-244; what
+    loss.backward(), AdvancedModel.py:299, derives in phases 3-4): loss = sum(out * G)."""
+    g = torch.Generator().manual_seed(808)
+    for (B, L, M, H, W, ks) in [(2, 4, 5, 10, 11, 9), (1, 7, 3, 14, 9, 9), (2, 6, 2, 9, 40, 5)]:
+        la = AM.LinearActivation(L, H, W)
+        conv = nn.Conv2d(L, L * M, kernel_size=(ks, ks), padding=(ks // 2, ks // 2))
+        ga = AM.LinearActivation(L * M, H, W)
+        pool = AM.BlockMinPooling(kernel_size=M, dim=1)
+        with torch.no_grad():
+            for p in (la.weight, la.bias, conv.weight, conv.bias, ga.weight, ga.bias):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+        t0 = torch.randn(B, L, H, W, generator=g)
+        u0 = torch.randn(B, L, H, W, generator=g) * 2
+        G = torch.randn(B, L, H, W, generator=g)
+        out = dict(t=npy(t0), unary=npy(u0), G=npy(G), mixtures=np.int64(M), ks=np.int64(ks),
+                   la_w=npy(la.weight), la_b=npy(la.bias), conv_w=npy(conv.weight), conv_b=npy(conv.bias),
+                   ga_w=npy(ga.weight), ga_b=npy(ga.bias))
+        for dtype, tag in ((torch.float32, ""), (torch.float64, "64")):
+            la, conv, ga = la.to(dtype), conv.to(dtype), ga.to(dtype)
+            for p in list(la.parameters()) + list(conv.parameters()) + list(ga.parameters()):
+                p.grad = None
+            t = t0.detach().clone().to(dtype).requires_grad_(True)
+            u = u0.detach().clone().to(dtype).requires_grad_(True)
+            smooth = pool(ga(conv(la(t))))
+            res = nn.LogSoftmax(dim=1)(torch.nn.functional.log_softmax(u, dim=1) - smooth)
+            (res * G.to(dtype)).sum().backward()
+            out.update({f"out{tag}": npy(res), f"dt{tag}": npy(t.grad), f"dunary{tag}": npy(u.grad),
+                        f"dla_w{tag}": npy(la.weight.grad), f"dla_b{tag}": npy(la.bias.grad),
+                        f"dconv_w{tag}": npy(conv.weight.grad), f"dconv_b{tag}": npy(conv.bias.grad),
+                        f"dga_w{tag}": npy(ga.weight.grad), f"dga_b{tag}": npy(ga.bias.grad)})
+        save(f"tailgrad_l{L}_m{M}_k{ks}", **out)
+
+
+class _GradUnary(nn.Module):
+    """Stands in for the unary stack: a stored synthetic unary that takes a gradient."""
+
+    def __init__(self, unary):
+        super().__init__()
+        self.unary = nn.Parameter(unary)
+
+    def forward(self, x):
+        return self.unary
+
+
+def gen_dpn_grad(AM):
+    """Autograd gradients of DPNModel.forward(phase=3) and (phase=4) with the unary CNN bypassed
+    (AdvancedModel.py:198-244, 299): the model's own 50x50 window, loss = sum(output * G)."""
+    g = torch.Generator().manual_seed(909)
+    H, W, L, M = 8, 9, 4, 5
+    torch.manual_seed(909)
+    model = AM.DPNModel(H, W, num_labels=L, num_mixture_filters=M)
+    unary = torch.randn(2, L, H, W, generator=g) * 2
+    img = torch.randn(2, 3, H, W, generator=g)
+    G = torch.randn(2, L, H, W, generator=g)
+    model.unary_terms_layers = _GradUnary(unary.clone())
+    with torch.no_grad():
+        model.local_activation_function.weight.copy_(1 + 0.2 * torch.randn(1, L, H, W, generator=g))
+        model.local_activation_function.bias.copy_(0.1 * torch.randn(1, L, H, W, generator=g))
+        model.local_convolution_layer.position_weight.fill_(-0.004)
+        model.local_convolution_layer.color_weight.fill_(-0.003)
+        # (the reference's init leaves the context layers at ~1e-2: scaled up so every gradient is well above rounding)
+        model.global_convolution_layer.weight.mul_(5)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    out = dict(img=npy(img), unary=npy(unary), G=npy(G), mixtures=np.int64(M), k=np.int64(50), ks=np.int64(9),
+               pw=np.float32(-0.004), cw=np.float32(-0.003),
+               la_w=npy(sd["local_activation_function.weight"]), la_b=npy(sd["local_activation_function.bias"]),
+               conv_w=npy(sd["global_convolution_layer.weight"]), conv_b=npy(sd["global_convolution_layer.bias"]),
+               ga_w=npy(sd["global_activation_function.weight"]), ga_b=npy(sd["global_activation_function.bias"]))
+    names = {"unary_terms_layers.unary": "dunary", "local_convolution_layer.position_weight": "dpw",
+             "local_convolution_layer.color_weight": "dcw", "local_activation_function.weight": "dla_w",
+             "local_activation_function.bias": "dla_b", "global_convolution_layer.weight": "dconv_w",
+             "global_convolution_layer.bias": "dconv_b", "global_activation_function.weight": "dga_w",
+             "global_activation_function.bias": "dga_b"}
+    for phase in (3, 4):
+        model.zero_grad()
+        res = model(img, phase=phase)
+        (res * G).sum().backward()
+        out[f"out_p{phase}"] = npy(res)
+        for pname, key in names.items():
+            p = dict(model.named_parameters())[pname]
+            out[f"{key}_p{phase}"] = npy(p.grad) if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+    save("dpngrad_h8_w9_l4", **out)
+
+
+def gen_fit_step(LC, AM):
+    """One optimiser step's worth of gradients the way DPNModel.fit accumulates them (AdvancedModel.py:295-303):
+    single-image forwards, loss = NLLLoss(weight=_calc_weights, ignore_index=255)(prediction, label) / batch_size,
+    backward per image, gradients summed over the batch_size images.  The forward is the reference's phase-4 data
+    flow with the label-context block an LxL matrix (Conv2d(L, L, 1)), K iterations of imported modules."""
+    g = torch.Generator().manual_seed(1010)
+    B, L, H, W, k, K = 4, 6, 12, 80, 3, 2
+    unary = torch.randn(B, L, H, W, generator=g) * 2
+    img = torch.randn(B, 3, H, W, generator=g)
+    labels = torch.randint(0, L, (B, H, W), generator=g)
+    labels[torch.rand(B, H, W, generator=g) < 0.05] = 255
+    labels[3] = 255                                         # an image without a valid pixel cannot go through the
+    labels[3, :4] = 1                                       # reference's loss (NaN): keep a few valid ones
+    compat = (1 - torch.eye(L)) + 0.01 * torch.randn(L, L, generator=g)
+    la_w = 1 + 0.2 * torch.randn(1, L, H, W, generator=g)
+    la_b = 0.1 * torch.randn(1, L, H, W, generator=g)
+    stub = _metrics_stub(AM, L)
+    weight = AM.DPNModel._calc_weights(stub, [labels[b].numpy() for b in range(B)])
+    out = dict(unary=npy(unary), img=npy(img), labels=labels.numpy().astype(np.int64), compat=npy(compat), la_w=npy(la_w),
+               la_b=npy(la_b), k=np.int64(k), iters=np.int64(K), pw=np.float32(-0.004), cw=np.float32(-0.003),
+               weight=npy(weight))
+    for dtype, tag in ((torch.float32, ""), (torch.float64, "64")):
+        local = LC.Conv2dLocal(H, W, L, k)
+        conv = nn.Conv2d(L, L, kernel_size=1, bias=False)
+        la = AM.LinearActivation(L, H, W)
+        with torch.no_grad():
+            local.position_weight.fill_(-0.004)
+            local.color_weight.fill_(-0.003)
+            conv.weight.copy_(compat.reshape(L, L, 1, 1))
+            la.weight.copy_(la_w)
+            la.bias.copy_(la_b)
+        conv, la = conv.to(dtype), la.to(dtype)
+        loss_function = nn.NLLLoss(weight=weight.to(dtype), ignore_index=255)
+        cdf = AM.DPNModel._color_distance(kernel_size=(k, k), channels=3)
+        U = unary.detach().clone().to(dtype).requires_grad_(True)
+        total = 0.0
+        for b in range(B):                                   # batch_size = B single-image micro-batches
+            u = U[b:b + 1]
+            cd = cdf(img[b:b + 1].to(dtype))
+            q = u
+            for _ in range(K):
+                msg = conv(la(local(q, cd)))
+                logq = nn.LogSoftmax(dim=1)(torch.nn.functional.log_softmax(u, dim=1) - msg)
+                q = torch.exp(logq)
+            loss = loss_function(logq, labels[b:b + 1]) / B
+            loss.backward()
+            total += loss.item()
+        out.update({f"loss{tag}": np.float64(total), f"dU{tag}": npy(U.grad), f"dpw{tag}": npy(local.position_weight.grad),
+                    f"dcw{tag}": npy(local.color_weight.grad), f"dcompat{tag}": npy(conv.weight.grad.reshape(L, L)),
+                    f"dla_w{tag}": npy(la.weight.grad), f"dla_b{tag}": npy(la.bias.grad)})
+    save("fitstep_l6_h12_w80_k3", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None, help="run one generator (e.g. meanfield_grad)")
@@ -269,8 +441,11 @@ def main():
     args = ap.parse_args()
     torch.set_num_threads(4)
     LC, AM = import_reference(args.reference)
-    if args.only == "meanfield_grad":
-        gen_meanfield_grad(LC, AM)
+    only = {"meanfield_grad": lambda: gen_meanfield_grad(LC, AM), "metrics": lambda: gen_metrics(AM),
+            "tail_grad": lambda: gen_tail_grad(AM), "dpn_grad": lambda: gen_dpn_grad(AM),
+            "fit_step": lambda: gen_fit_step(LC, AM)}
+    if args.only is not None:
+        only[args.only]()
         return
     gen_color_distance(AM)
     gen_local(LC)
@@ -278,6 +453,10 @@ def main():
     gen_dpn(AM)
     gen_meanfield(LC, AM)
     gen_meanfield_grad(LC, AM)
+    gen_metrics(AM)
+    gen_tail_grad(AM)
+    gen_dpn_grad(AM)
+    gen_fit_step(LC, AM)
 
 
 if __name__ == "__main__":

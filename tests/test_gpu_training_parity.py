@@ -1,0 +1,182 @@
+"""GPU parity of the training-side paths with the oracle and with fixtures made by the imported reference:
+the loop backward at training size, workspace hygiene of the loop backward, non-finite gradients, the metric
+and class-weight conventions, one optimiser step of `training.fit`, and the strict marginal figure on the
+stress golden.  Everything goes through the C ABI (semantic_segmentation_amd.ops / _lib)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, golden_files, load
+from test_gpu_parity import dev, host, make_inputs, scalar, strict_rel_err_on_marginals
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def S():
+    import semantic_segmentation_amd as S
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return S
+
+
+def _loop_inputs(shape, seed):
+    B, C, H, W, k = shape
+    unary, img, _ = make_inputs(shape, seed)
+    rng = np.random.default_rng(seed + 100)
+    compat = ((1 - np.eye(C)) + 0.01 * rng.standard_normal((C, C))).astype(np.float32)
+    aw = (1 + 0.2 * rng.standard_normal((1, C, H, W))).astype(np.float32)
+    ab = (0.1 * rng.standard_normal((1, C, H, W))).astype(np.float32)
+    G = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    return unary, img, compat, aw, ab, G
+
+
+@pytest.mark.parametrize("iters", [1, 2])
+def test_loop_backward_at_training_size_vs_oracle(iters, S, oracle):
+    """21 labels, 512x512, 7x7, batch 2 (the training configuration's image size), affine + label matrix, with the
+    forward's iterates kept: dU of every image, and d compat / d affine / both scalars as sums over the images, against
+    oracle.meanfield_backward run image by image (AdvancedModel.py:222-244, 298-299)."""
+    shape = (2, 21, 512, 512, 7)
+    B, C, H, W, k = shape
+    unary, img, compat, aw, ab, G = _loop_inputs(shape, 81)
+    pw, cw = -0.004, -0.003
+    its = S.ops.meanfield_forward_iterates(dev(unary), dev(img), scalar(pw), scalar(cw), k, iters, dev(aw), dev(ab), dev(compat))
+    du, dpar, daw, dab, dcompat = S.ops.meanfield_backward(dev(unary), dev(img), scalar(pw), scalar(cw), k, iters, dev(G),
+                                                           dev(aw), dev(ab), dev(compat), logq_iterates=its)
+    want = {"dcompat": 0.0, "daw": 0.0, "dab": 0.0, "dpw": 0.0, "dcw": 0.0}
+    for b in range(B):
+        r = oracle.meanfield_backward(unary[b:b + 1], img[b:b + 1], pw, cw, k, iters, G[b:b + 1], aw, ab, compat)
+        assert_close(host(its[iters - 1][b:b + 1]), r["logq"], RTOL, f"logq of image {b}")
+        assert_close(host(du[b:b + 1]), r["dU"], RTOL, f"dU of image {b}")
+        for key in want:
+            want[key] = want[key] + r[key]
+    assert_close(host(dcompat), want["dcompat"], RTOL, "d compat")
+    assert_close(host(daw).reshape(C, H, W), want["daw"], RTOL, "d affine weight")
+    assert_close(host(dab).reshape(C, H, W), want["dab"], RTOL, "d affine bias")
+    assert abs(float(dpar[0]) - want["dpw"]) <= 2e-4 * abs(want["dpw"]), (float(dpar[0]), want["dpw"])
+    assert abs(float(dpar[1]) - want["dcw"]) <= 2e-4 * abs(want["dcw"]), (float(dpar[1]), want["dcw"])
+    # without the iterates the call recomputes the loop: same gradients
+    again = S.ops.meanfield_backward(dev(unary), dev(img), scalar(pw), scalar(cw), k, iters, dev(G), dev(aw), dev(ab), dev(compat))
+    assert_close(host(again[0]), host(du), 1e-6, "dU, loop recomputed inside the call")
+
+
+def test_loop_backward_does_not_trust_a_stale_plan_tag(S, oracle):
+    """The nested operator calls of mfl_meanfield_backward keep their address tables (and the tag that says so) in
+    the middle of the call's workspace.  A block that went back to an allocator can return with that tag intact and
+    the tables overwritten: everything but the tag bytes is scribbled over between two calls on one caller-owned
+    buffer, and the second call must still give the first call's gradients."""
+    from semantic_segmentation_amd import _lib
+    lib, ptr = _lib.lib, _lib.ptr
+    shape = (2, 8, 70, 96, 5)
+    B, C, H, W, k = shape
+    iters = 2
+    unary, img, compat, aw, ab, G = _loop_inputs(shape, 83)
+    U, I, GG, AW, AB, CM = dev(unary), dev(img), dev(G), dev(aw), dev(ab), dev(compat)
+    pw, cw = scalar(0.3), scalar(-0.7)
+    n = int(lib.mfl_workspace_bytes(_lib.OP_MEANFIELD_BACKWARD, B, C, H, W, k, iters))
+    sub_bytes = max(int(lib.mfl_workspace_bytes(op, B, C, H, W, k, iters))
+                    for op in (_lib.OP_MEANFIELD_FORWARD, _lib.OP_LOCAL_FORWARD, _lib.OP_LOCAL_BACKWARD))
+    sub = n - (sub_bytes + 255) // 256 * 256               # the nested calls' workspace is the last block carved
+    ws = torch.zeros(n, dtype=torch.uint8, device="cuda")
+
+    def run():
+        du, dpar = torch.full_like(U, float("nan")), torch.empty(2, device="cuda")
+        daw, dab, dcm = torch.empty_like(AW), torch.empty_like(AB), torch.empty_like(CM)
+        rc = lib.mfl_meanfield_backward(ptr(U), ptr(I), ptr(pw), ptr(cw), ptr(AW), ptr(AB), ptr(CM), None, ptr(GG), ptr(du),
+                                        ptr(dpar), ptr(daw), ptr(dab), ptr(dcm), B, C, H, W, k, iters, ptr(ws), n,
+                                        _lib.stream_of(U))
+        assert rc == 0, lib.mfl_error_string(rc).decode()
+        torch.cuda.synchronize()
+        return [host(t) for t in (du, dpar, daw, dab, dcm)]
+
+    first = run()
+    tag = ws[sub:sub + 32].clone()
+    assert tag.any(), "the nested calls stamp their plan tag at the start of their workspace"
+    g = torch.Generator(device="cuda").manual_seed(9)
+    ws.copy_(torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda", generator=g))
+    ws[sub:sub + 32] = tag                                     # the tag survives, nothing it vouches for does
+    second = run()
+    for a, b, name in zip(second, first, ("dU", "dparams", "d affine w", "d affine b", "d compat")):
+        assert np.array_equal(a, b), name
+    ref = oracle.meanfield_backward(unary, img, 0.3, -0.7, k, iters, G, aw, ab, compat)
+    assert_close(second[0], ref["dU"], RTOL, "dU after the scribble")
+
+
+def test_local_backward_propagates_non_finite_gradients(S):
+    """One Inf in dy: the reference's autograd would hand back non-finite gradients; the fixed-point scatter must not
+    turn them into finite numbers (its scale is derived from max|dy*x|, which is then not finite)."""
+    shape = (1, 8, 70, 96, 5)
+    x, img, dy = make_inputs(shape, 85)
+    dy[0, 3, 20, 30] = np.inf
+    dx, dpar, _ = S.ops.local_backward(dev(x), scalar(0.3), scalar(-0.7), 5, dev(dy), image=dev(img))
+    assert not torch.isfinite(dx).any(), "every dx is NaN when the gradient has no fixed-point scale"
+    assert not torch.isfinite(dpar).all()
+    dy[0, 3, 20, 30] = np.nan
+    dx, _, _ = S.ops.local_backward(dev(x), scalar(0.3), scalar(-0.7), 5, dev(dy), image=dev(img))
+    assert not torch.isfinite(dx).any()
+
+
+def test_metrics_against_reference_fixture(S):
+    """mfl_iou_counts + ops.intersection_over_union / mean_intersection_over_union and training.class_weights against
+    outputs of the imported DPNModel.calc_intersection_over_union, calc_mean_intersection_over_union and _calc_weights
+    (AdvancedModel.py:427-517; tests/golden/make_golden.py: gen_metrics)."""
+    from semantic_segmentation_amd import training
+    d = load(golden_files("metrics")[0])
+    C = int(d["num_labels"])
+    for ci in range(3):
+        pred, target = dev(d[f"pred{ci}"]), dev(d[f"target{ci}"])
+        for bg in (False, True):
+            got = host(S.ops.intersection_over_union(pred, target, C, include_background=bg))
+            assert np.allclose(got, d[f"iou{ci}_bg{int(bg)}"], rtol=1e-6, atol=0), (ci, bg)
+            mean = S.ops.mean_intersection_over_union(pred, target, C, bg)
+            assert abs(mean - float(d[f"miou{ci}_bg{int(bg)}"])) < 1e-6, (ci, bg)
+        w = host(training.class_weights(target, C))
+        assert np.allclose(w, d[f"weights{ci}"], rtol=1e-6, atol=0), ci
+
+
+def test_fit_first_step_gradients_equal_the_reference_accumulation(S):
+    """training.fit on ONE batched tensor against the gradients the reference's loop accumulates over batch_size
+    single-image forwards with loss / batch_size (AdvancedModel.py:295-303; tests/golden/make_golden.py: gen_fit_step):
+    dU, d position_weight, d color_weight, d compat, d LinearActivation after the first backward."""
+    from semantic_segmentation_amd import training
+    d = load(golden_files("fitstep")[0])
+    B, L, H, W = d["unary"].shape
+    k, iters = int(d["k"]), int(d["iters"])
+    model = S.MeanFieldLocal(H, W, L, k, iters=iters, compat=True, affine=True).cuda()
+    with torch.no_grad():
+        model.local_convolution_layer.position_weight.fill_(float(d["pw"]))
+        model.local_convolution_layer.color_weight.fill_(float(d["cw"]))
+        model.compat.copy_(dev(d["compat"]))
+        model.local_activation_function.weight.copy_(dev(d["la_w"]))
+        model.local_activation_function.bias.copy_(dev(d["la_b"]))
+    U = dev(d["unary"]).requires_grad_(True)
+    labels = dev(d["labels"])
+    weight = training.class_weights(labels, L)
+    assert np.allclose(host(weight), d["weight"], rtol=1e-6, atol=0)
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)            # the step changes nothing: the gradients stay to be read
+    history = training.fit(model, opt, lambda: [(U, dev(d["img"]), labels)], epochs=1, weight=weight)
+    assert abs(history[0] - float(d["loss64"])) <= 1e-4 * abs(float(d["loss64"]))
+    assert_close(host(U.grad), d["dU64"], RTOL, "dU")
+    assert_close(host(model.compat.grad), d["dcompat64"], RTOL, "d compat")
+    assert_close(host(model.local_activation_function.weight.grad), d["dla_w64"], RTOL, "d affine weight")
+    assert_close(host(model.local_activation_function.bias.grad), d["dla_b64"], RTOL, "d affine bias")
+    for p, key in ((model.local_convolution_layer.position_weight, "dpw64"), (model.local_convolution_layer.color_weight, "dcw64")):
+        want = float(d[key][0])
+        assert abs(float(p.grad) - want) <= 2e-4 * abs(want), (key, float(p.grad), want)
+
+
+def test_strict_marginal_figure_on_the_stress_golden(S):
+    """The mean-field golden with potentials ten times the reference's initial scale (pw = 0.05, cw = -0.02, 4x4
+    window): the elementwise figure max |Q - Q_ref| / Q_ref against the reference's float64 run, with no tensor-scale
+    floor.  The bar is 1e-4, or the figure of the reference's own float32 run where that is already above it (an fp32
+    summation cannot be asked to beat the fp32 reference)."""
+    path = [p for p in golden_files("meanfield") if "l5_h8_w8_k4" in p][0]
+    d = load(path)
+    k = int(d["k"])
+    for it in (1, 2, 5, 10):
+        lq = host(S.ops.meanfield_forward(dev(d["unary"]), dev(d["img"]), scalar(d["pw"]), scalar(d["cw"]), k, it,
+                                          dev(d["la_w"]), dev(d["la_b"]), dev(d["compat"])))
+        mine = strict_rel_err_on_marginals(lq, d[f"logq64_it{it}"])
+        reference_fp32 = strict_rel_err_on_marginals(d[f"logq_it{it}"], d[f"logq64_it{it}"])
+        assert mine < max(1e-4, 2 * reference_fp32), (it, mine, reference_fp32)

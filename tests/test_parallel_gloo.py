@@ -101,3 +101,18 @@ def test_sharded_update_with_one_rank_is_plain_sgd():
     opt.step()
     sharded.all_gather_parameters()
     assert torch.allclose(w.detach(), w0 - 0.5)
+
+
+def test_dist_worker_script_over_gloo():
+    """tests/dist_worker.py (what the multi-GPU test starts once per GPU with backend nccl) with two fresh CPU
+    ranks over gloo: same launcher, same checks, only the transport differs."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "--backend", "gloo", "--numel", "1001"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout

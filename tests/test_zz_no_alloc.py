@@ -40,8 +40,10 @@ def _both(shape, k, iters, seed):
 def test_noalloc_matches_workspace_entry_point_twice():
     assert torch.cuda.is_available()
     # first call: 11x11 stream kernels (weight table, two padded buffers, records); second, smaller: the
-    # diagonal kernels on what the first call left in the buffer
-    for shape, k, iters, seed in (((1, 8, 64, 128), 11, 2, 5), ((2, 21, 96, 112), 7, 3, 6), ((1, 5, 40, 72), 3, 2, 7)):
+    # diagonal kernels on what the first call left in the buffer; last: the first shape again, whose plan tag the
+    # calls in between replaced (the tables are rebuilt, not trusted)
+    for shape, k, iters, seed in (((1, 8, 64, 128), 11, 2, 5), ((2, 21, 96, 112), 7, 3, 6), ((1, 5, 40, 72), 3, 2, 7),
+                                  ((1, 8, 64, 128), 11, 2, 5)):
         got, want = _both(shape, k, iters, seed)
         assert np.isfinite(got).all()
         assert np.array_equal(got, want), f"{shape} k={k}: max diff {np.abs(got - want).max()}"
