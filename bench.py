@@ -23,7 +23,9 @@ Prints one JSON line: metric = mean-field iter*Mpixel/s over the whole job, plus
                  512x1024 crop of image 0 (rank 0, N = 1 only), median of 5
   other_configs  short measurements of BASELINE.json configs[1] and configs[4] (N = 1 only) and of
                  configs[2] (training step: forward, NLL with 255-ignore, backward, one flat all-reduce
-                 of the potential-parameter gradients)
+                 of the potential-parameter gradients; at N = 1 its parameter gradients for image 0 are checked
+                 against the CPU oracle outside the timed region) and, at N > 1, of the reduce-scatter /
+                 all-gather exchange of the per-pixel affine parameters
 """
 import argparse
 import json
@@ -259,7 +261,7 @@ def run_inference(job, key, steps, warmup, with_cpu):
     return res
 
 
-def run_training(job, key, steps, warmup):
+def run_training(job, key, steps, warmup, check=False):
     """CONFIGS[key] as a training step on the rank's shard: forward (mean-field module), NLL with
     255-ignore (AdvancedModel.py:164, 298), backward, ONE flat all-reduce of the potential-parameter
     gradients (AdvancedModel.py:298-303 accumulates before optimizer.step())."""
@@ -303,11 +305,78 @@ def run_training(job, key, steps, warmup):
     assert all(torch.isfinite(gr).all() for gr in grads)
     if job.rank != 0:
         return None
-    return {"workload": f"{cfg['what']}: {L} labels, {H}x{W}, global batch {batch}, {k}x{k} window, "
-                        f"{iters} mean-field iteration(s), fwd + NLL(255-ignore) + bwd + flat all-reduce ({cfg['ref']})",
-            "value": round(batch * H * W * steps / 1e6 / elapsed, 2), "unit": "Mpixel/s (fwd+bwd)",
-            "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "batch_per_gpu": hi - lo,
-            "allreduce_floats": int(sum(gr.numel() for gr in grads))}
+    res = {"workload": f"{cfg['what']}: {L} labels, {H}x{W}, global batch {batch}, {k}x{k} window, "
+                       f"{iters} mean-field iteration(s), fwd + NLL(255-ignore) + bwd + flat all-reduce ({cfg['ref']})",
+           "value": round(batch * H * W * steps / 1e6 / elapsed, 2), "unit": "Mpixel/s (fwd+bwd)",
+           "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "batch_per_gpu": hi - lo,
+           "allreduce_floats": int(sum(gr.numel() for gr in grads))}
+    if check:
+        res["oracle_check"] = training_oracle_check(model, cfg, unary[:1], img[:1], labels[:1], loss_fn)
+    return res
+
+
+def training_oracle_check(model, cfg, unary, img, labels, loss_fn):
+    """Outside the timed region: the gradients of the two potential parameters (and of the label matrix) for the loss
+    of image 0 alone, from the library's backward and from the CPU oracle's restatement of the same loop backward
+    (AdvancedModel.py:222-244, 298-299).  Raises if they disagree beyond 2e-4."""
+    from oracle import oracle as O
+    O.build()
+    k, iters = cfg["window"], cfg["iters"]
+    model.zero_grad(set_to_none=True)
+    logq = model(unary, img)
+    logq.retain_grad()
+    loss_fn(logq, labels).backward()
+    local = model.local_convolution_layer
+    got = {"dpw": float(local.position_weight.grad), "dcw": float(local.color_weight.grad)}
+    ref = O.meanfield_backward(unary.cpu().numpy(), img.cpu().numpy(), POS_W, COL_W, k, iters, logq.grad.cpu().numpy(), None, None,
+                               model.compat.detach().cpu().numpy())
+    err = {key: abs(got[key] - ref[key]) / (abs(ref[key]) + 1e-30) for key in got}
+    dc = model.compat.grad.cpu().numpy().astype(np.float64)
+    err["dcompat"] = float(np.abs(dc - ref["dcompat"]).max() / (np.abs(ref["dcompat"]).max() + 1e-30))
+    if max(err.values()) > 2e-4:
+        raise SystemExit(f"config 3: the library's parameter gradients differ from the oracle's: {err}")
+    return {"what": "d position_weight, d color_weight, d compat of image 0's loss against the CPU oracle",
+            "d_position_weight": got["dpw"], "d_color_weight": got["dcw"],
+            "relative_error": {key: float(f"{v:.2e}") for key, v in err.items()}}
+
+
+def run_exchange(job, reps=5):
+    """The bandwidth-bound exchange of data-parallel training: the per-pixel affine parameters of the reference's
+    model at 21 labels / 512x512 (local_activation_function 2*L*H*W floats = 44 MB, global_activation_function
+    2*L*M*H*W = 220 MB; AdvancedModel.py:38-56, 138, 145) through parallel.ShardedUpdate: reduce-scatter of the
+    gradients + all-gather of the parameters per step.  Reports the time per step (max over ranks) and the bytes
+    each rank sends per second."""
+    import semantic_segmentation_amd as S
+    L, M, H, W = 21, 5, 512, 512
+    dev = job.device
+    params = [torch.nn.Parameter(torch.zeros(n, device=dev)) for n in (L * H * W, L * H * W, L * M * H * W, L * M * H * W)]
+    for p in params:
+        p.grad = torch.ones_like(p)
+    sharded = S.parallel.ShardedUpdate(params)
+
+    def step():
+        sharded.reduce_scatter_gradients()
+        with torch.no_grad():
+            sharded.shard.add_(sharded.shard.grad, alpha=-1e-3)      # the optimiser's update of this rank's slice
+        sharded.all_gather_parameters()
+
+    step()
+    job.fence()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    job.fence()
+    elapsed = job.max_over_ranks(time.perf_counter() - t0) / reps
+    want = -1e-3 * (reps + 1) * job.world
+    assert abs(float(params[0][0]) - want) < 1e-6 * abs(want) + 1e-9, "sharded update gave the wrong parameters"
+    if job.rank != 0:
+        return None
+    nbytes = sharded.numel * 4
+    sent = 2 * nbytes * (job.world - 1) / job.world            # reduce-scatter + all-gather, per rank
+    return {"workload": "per-pixel affine parameters, 21 labels / 5 mixtures / 512x512: reduce-scatter of the gradients, "
+                        "update of 1/N of the parameters, all-gather (RCCL)",
+            "buffer_MB": round(nbytes / 1e6, 1), "ms_per_step": round(elapsed * 1e3, 3),
+            "sent_GBps_per_rank": round(sent / elapsed / 1e9, 1)}
 
 
 def run_reference_default(job):
@@ -347,9 +416,14 @@ def main():
     others = {}
     if not args.only:
         torch.cuda.empty_cache()
-        r = run_training(job, "c3", steps=5, warmup=2)
+        r = run_training(job, "c3", steps=5, warmup=2, check=job.world == 1 and not args.no_cpu_baseline)
         if r:
             others["config3_training"] = r
+        if job.world > 1:
+            torch.cuda.empty_cache()
+            r = run_exchange(job)
+            if r:
+                others["affine_parameter_exchange"] = r
         if job.world == 1:
             for key, st, wu in (("c2", 5, 2), ("c5", 2, 1)):
                 torch.cuda.empty_cache()

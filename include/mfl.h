@@ -228,6 +228,33 @@ int mfl_label_context_forward(const float *t, const float *la_w, const float *la
                               size_t workspace_bytes, mfl_stream_t stream);
 
 /*
+ * Gradients of mfl_label_context_forward: what autograd derives for the same chain
+ * (local_activation_function -> global_convolution_layer -> global_activation_function ->
+ * BlockMinPooling -> combine + LogSoftmax, AdvancedModel.py:223, 232-244) when
+ * loss.backward() (AdvancedModel.py:299) runs in training phases 3 and 4
+ * (AdvancedModel.py:364-381).  The minimum over the mixtures hands its gradient to the
+ * arg-min mixture (the first one on ties, as torch.min(dim)).
+ *   grad_logq:   dL/dlogq, [B][L][H][W], or NULL
+ *   grad_smooth: dL/dsmooth, [B][L][H][W], or NULL (phase 3 ends in log_softmax(smooth),
+ *                AdvancedModel.py:237-238: its gradient enters here); not both NULL
+ *   d_t, d_unary: [B][L][H][W], overwritten
+ *   d_conv_w: [L*M][L][ks][ks], overwritten    d_conv_b: [L*M], non-NULL exactly when conv_b is
+ *   d_la_w, d_la_b: [L][H][W], non-NULL exactly when la_w is
+ *   d_ga_w, d_ga_b: [L*M][H][W], non-NULL exactly when ga_w is
+ * The forward is recomputed inside the call; the data gradient and the weight gradient of the
+ * convolution run as GEMMs on the fp32 matrix instructions.  Every sum over images and pixels
+ * has a fixed order (no atomics): the gradients are reproducible bit for bit.
+ * Workspace: mfl_label_context_backward_workspace_bytes() (0: unsupported or too large).
+ */
+size_t mfl_label_context_backward_workspace_bytes(int B, int L, int M, int H, int W, int ks);
+int mfl_label_context_backward(const float *t, const float *la_w, const float *la_b, const float *conv_w,
+                               const float *conv_b, const float *ga_w, const float *ga_b, const float *unary,
+                               const float *grad_logq, const float *grad_smooth, float *d_t, float *d_unary,
+                               float *d_la_w, float *d_la_b, float *d_conv_w, float *d_conv_b, float *d_ga_w,
+                               float *d_ga_b, int B, int L, int M, int H, int W, int ks, void *workspace,
+                               size_t workspace_bytes, mfl_stream_t stream);
+
+/*
  * Per-class pixel counts behind the reference's intersection-over-union
  * (DPNModel.calc_intersection_over_union, AdvancedModel.py:448-485):
  *   counts[0][c] = #(pred == c and target == c)    intersection

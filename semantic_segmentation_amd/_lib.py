@@ -37,6 +37,8 @@ SIGNATURES = {
     "mfl_meanfield_forward_noalloc": (_c_int, [_c_void] * 8 + [_c_int] * 6 + [_c_void]),
     "mfl_label_context_workspace_bytes": (_c_size, [_c_int] * 6),
     "mfl_label_context_forward": (_c_int, [_c_void] * 10 + [_c_int] * 6 + [_c_void, _c_size, _c_void]),
+    "mfl_label_context_backward_workspace_bytes": (_c_size, [_c_int] * 6),
+    "mfl_label_context_backward": (_c_int, [_c_void] * 18 + [_c_int] * 6 + [_c_void, _c_size, _c_void]),
     "mfl_iou_counts": (_c_int, [_c_void, _c_void, _c_void, _c_size, _c_int, _c_void]),
     "mfl_argmax_labels": (_c_int, [_c_void, _c_void] + [_c_int] * 4 + [_c_void]),
 }

@@ -19,6 +19,20 @@
 // Epilogue: register v of block m of lane (p, h) is output channel m*L + l, l = 8 (v/4) + 4 h + v%4, of the lane's
 // pixel: bias, per-pixel affine, min over m, then the two softmaxes with the maxima and sums exchanged between
 // the two lanes of a pixel.
+//
+// Backward (C ABI: mfl_label_context_backward; what autograd derives for phases 3-4, AdvancedModel.py:299): the
+// forward runs again and keeps, per (image, label, pixel), the arg-min mixture and the convolution's value there
+// (torch.min(dim) routes its gradient to that mixture only, AdvancedModel.py:35); then
+//   pre          dz = G - exp(logq) * sum G, d unary, d smooth = -dz (+ a caller's gradient of smooth), the gradient of
+//                the convolution's output (non-zero in the arg-min mixture only) into zero-padded planes, d ga_w, d ga_b
+//   bias         d conv_b = plane sums of that gradient
+//   data         d a = Conv2d(L*M -> L) of those planes with the flipped, transposed weights: the same implicit GEMM,
+//                one block of 32 rows (context_conv_kernel<1, plain epilogue>)
+//   affine       d t = la_w * d a, d la_w = sum_b d a * t, d la_b = sum_b d a
+//   weights      d conv_w[o][i][ky][kx] = sum over pixels of (gradient plane o) * (padded activation plane i shifted by
+//                the tap): a GEMM [L*M x pixels] . [pixels x L*k*k] on the same instruction, pixels split into slices
+//                whose partial sums are added in a fixed order (context_wgrad_kernel, context_wgrad_reduce_kernel)
+// Sums over images and pixels have a fixed order: the gradients are reproducible bit for bit.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -82,11 +96,16 @@ __global__ void label_context_weights_kernel(const float *__restrict__ conv_w, f
     }
 }
 
-template <int M>
+// MODE 0: the fused forward epilogue (optionally keeping the arg-min mixture `amin` and the convolution's value
+//         there `cmin`, for the backward)
+// MODE 1: plain convolution: out[b][l][y][x] = accumulator (M = 1), written to `smooth`
+// Cin: channels of the padded input planes (L for the forward; L*M for the data gradient, whose rows are the L labels)
+template <int M, int MODE>
 __global__ void __launch_bounds__(64 * kWavesPerGroup)
 label_context_kernel(const float *__restrict__ apad, const float *__restrict__ w2, const int *__restrict__ koff,
                      const float *__restrict__ conv_b, const float *__restrict__ ga_w, const float *__restrict__ ga_b,
-                     const float *__restrict__ unary, float *__restrict__ smooth, float *__restrict__ logq, int B, int L, int H,
+                     const float *__restrict__ unary, float *__restrict__ smooth, float *__restrict__ logq,
+                     unsigned char *__restrict__ amin, float *__restrict__ cmin, int B, int L, int Cin, int H,
                      int W, int Wp, int plane, int KKp, int tiles_per_row)
 {
     constexpr int R = 32 * M;
@@ -114,7 +133,7 @@ label_context_kernel(const float *__restrict__ apad, const float *__restrict__ w
         const int xc = x < W ? x : W - 1;
         img[tt] = b;
         pixl[tt] = y * W + xc;
-        base[tt] = b * L * plane + y * Wp + xc;              // window origin of the pixel in the padded planes
+        base[tt] = b * Cin * plane + y * Wp + xc;            // window origin of the pixel in the padded planes
     }
     f16v d[kTilesPerWave][M];
 #pragma unroll
@@ -154,6 +173,18 @@ label_context_kernel(const float *__restrict__ apad, const float *__restrict__ w
         }
     }
 
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int tt = 0; tt < kTilesPerWave; ++tt) {
+            if (!ok[tt]) continue;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int l = 8 * (v / 4) + 4 * h + (v % 4);
+                if (l < L) smooth[((size_t)img[tt] * L + l) * HW + pixl[tt]] = d[tt][0][v];
+            }
+        }
+        return;
+    }
     auto other_half = [&](float v) {
         return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, v)));
     };
@@ -168,15 +199,22 @@ label_context_kernel(const float *__restrict__ apad, const float *__restrict__ w
             const int l = 8 * (v / 4) + 4 * h + (v % 4);
             const bool valid = l < L;
             const int lc = valid ? l : L - 1;
-            float mn = INFINITY;
+            float mn = INFINITY, cv_at = 0.f;
+            int m_at = 0;
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 const int oc = m * L + lc;
-                float c = d[tt][m][v] + (conv_b ? conv_b[oc] : 0.f);
+                const float cv = d[tt][m][v] + (conv_b ? conv_b[oc] : 0.f);
+                float c = cv;
                 if (ga_w) c = fmaf(ga_w[(size_t)oc * HW + l0], c, ga_b[(size_t)oc * HW + l0]);
-                mn = fminf(mn, c);
+                if (m == 0 || c < mn) { mn = c; m_at = m; cv_at = cv; }      // (the first minimum, as torch.min(dim))
             }
             sm[v] = mn;
+            if (amin && valid && ok[tt]) {
+                const size_t o = ((size_t)img[tt] * L + lc) * HW + l0;
+                amin[o] = (unsigned char)m_at;
+                cmin[o] = cv_at;
+            }
             u[v] = valid ? unary[((size_t)img[tt] * L + lc) * HW + l0] : -INFINITY;
             mu = fmaxf(mu, u[v]);
         }
@@ -212,12 +250,205 @@ label_context_kernel(const float *__restrict__ apad, const float *__restrict__ w
     }
 }
 
+// ------------------------------------------------------------------ backward kernels
+
+// One thread per pixel of the image plane, looping over the batch (so the sums over images have a fixed order).
+//   dz = G - exp(logq) * sum_c G (LogSoftmax, AdvancedModel.py:244); d unary = dz - softmax(unary) * sum_c dz (:242);
+//   d smooth = gs - dz; the arg-min mixture m* of (b, l, pixel) receives it (BlockMinPooling, :35):
+//   gpad[b][m* L + l][y + p][x + p] = ga_w * d smooth (the planes were zeroed: the other mixtures stay 0);
+//   d ga_w[m* L + l][pixel] += d smooth * conv value there, d ga_b += d smooth (zeroed by the caller).
+// grad_logq / grad_smooth: either may be NULL (not both).
+__global__ void __launch_bounds__(256)
+context_pre_kernel(const float *__restrict__ grad_logq, const float *__restrict__ grad_smooth, const float *__restrict__ logq,
+                   const float *__restrict__ unary, const unsigned char *__restrict__ amin, const float *__restrict__ cmin,
+                   const float *__restrict__ ga_w, float *__restrict__ gpad, float *__restrict__ d_unary, float *__restrict__ d_ga_w,
+                   float *__restrict__ d_ga_b, int B, int L, int M, int H, int W, int HpG, int WpG, int p)
+{
+    const int HW = H * W;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= HW) return;
+    const int y = pix / W, x = pix - y * W;
+    const size_t gplane = (size_t)HpG * WpG;
+    for (int b = 0; b < B; ++b) {
+        const size_t base = (size_t)b * L * HW + pix;
+        float sg = 0.f, mx = -INFINITY;
+        for (int l = 0; l < L; ++l) {
+            if (grad_logq) sg += grad_logq[base + (size_t)l * HW];
+            mx = fmaxf(mx, unary[base + (size_t)l * HW]);
+        }
+        float sdz = 0.f, se = 0.f;
+        for (int l = 0; l < L; ++l) {
+            const size_t o = base + (size_t)l * HW;
+            if (grad_logq) sdz += grad_logq[o] - __expf(logq[o]) * sg;
+            se += __expf(unary[o] - mx);
+        }
+        const float rse = 1.f / se;
+        for (int l = 0; l < L; ++l) {
+            const size_t o = base + (size_t)l * HW;
+            const float dz = grad_logq ? grad_logq[o] - __expf(logq[o]) * sg : 0.f;
+            d_unary[o] = dz - __expf(unary[o] - mx) * rse * sdz;
+            const float ds = (grad_smooth ? grad_smooth[o] : 0.f) - dz;
+            const int oc = (int)amin[o] * L + l;
+            const size_t oa = (size_t)oc * HW + pix;
+            float dconv = ds;
+            if (ga_w) {
+                dconv = ga_w[oa] * ds;
+                d_ga_w[oa] = fmaf(ds, cmin[o], d_ga_w[oa]);
+                d_ga_b[oa] += ds;
+            }
+            gpad[((size_t)b * L * M + oc) * gplane + (size_t)(y + p) * WpG + x + p] = dconv;
+        }
+    }
+}
+
+// d conv_b[oc] = sum over images and pixels of the gradient planes (the padding adds zeros): one workgroup per
+// output channel, a fixed strided order per thread, then a fixed tree.
+__global__ void __launch_bounds__(256)
+context_bias_grad_kernel(const float *__restrict__ gpad, float *__restrict__ d_conv_b, int B, int LM, size_t gplane)
+{
+    __shared__ float sh[256];
+    const int oc = blockIdx.x;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float *pl = gpad + ((size_t)b * LM + oc) * gplane;
+        for (size_t i = threadIdx.x; i < gplane; i += 256) s += pl[i];
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) d_conv_b[oc] = sh[0];
+}
+
+// Weights of the data gradient: d a = Conv2d(L*M -> L, ks x ks, pad ks/2) of the gradient planes with
+// wt[kk][i] = conv_w[o][i][ks-1-ky][ks-1-kx], kk = (o*ks + ky)*ks + kx (zero for i >= L and kk >= KK2);
+// koff2[kk] = offset of tap kk in the gradient planes.
+__global__ void context_dgrad_weights_kernel(const float *__restrict__ conv_w, float *__restrict__ wt, int *__restrict__ koff2, int L,
+                                             int LM, int ks, int KK2, int KK2p, int gplane, int WpG)
+{
+    const size_t n = (size_t)KK2p * 32;
+    const int kk2 = ks * ks;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int kk = (int)(idx >> 5), i = (int)(idx & 31);
+        float v = 0.f;
+        int off = 0;
+        if (kk < KK2) {
+            const int o = kk / kk2, rem = kk - o * kk2, ky = rem / ks, kx = rem - ky * ks;
+            if (i < L) v = conv_w[(((size_t)o * L + i) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)];
+            off = o * gplane + ky * WpG + kx;
+        }
+        wt[idx] = v;
+        if (i == 0) koff2[kk] = off;
+    }
+}
+
+// d t = la_w * d a;  d la_w = sum_b d a * t;  d la_b = sum_b d a  (LinearActivation, AdvancedModel.py:52-56).  One thread per
+// (label, pixel), looping over the batch.  la_w NULL: d t = d a only.
+__global__ void __launch_bounds__(256)
+context_affine_grad_kernel(const float *__restrict__ da, const float *__restrict__ t, const float *__restrict__ la_w,
+                           float *__restrict__ d_t, float *__restrict__ d_la_w, float *__restrict__ d_la_b, int B, size_t LHW)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= LHW) return;
+    const float w = la_w ? la_w[i] : 1.f;
+    float sw = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float g = da[(size_t)b * LHW + i];
+        d_t[(size_t)b * LHW + i] = w * g;
+        sw = fmaf(g, t[(size_t)b * LHW + i], sw);
+        sb += g;
+    }
+    if (la_w) { d_la_w[i] = sw; d_la_b[i] = sb; }
+}
+
+// Weight gradient: D[row][col] = sum over pixels of g[row][pixel] * a[col][pixel], rows r = 32 m + l (gradient plane
+// m*L + l), columns = 32 consecutive taps kk = (i*ks + ky)*ks + kx of one column block: a[col][pixel] is the padded
+// activation plane i shifted by (ky, kx).  One wave per (column block, pixel slice); a slice is a run of row tiles
+// (64 consecutive pixels of one image row).  Per matrix instruction lane (p, h) supplies row / column p at pixel
+// x0 + 32 h + j: every lane walks 32 consecutive floats of its own plane row, four at a time.  The gradient planes
+// have a row pitch that covers the last, partial tile of an image row with zeros; what the activation planes hold
+// there is multiplied by those zeros.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int M>
+__global__ void __launch_bounds__(64 * kWavesPerGroup)
+context_wgrad_kernel(const float *__restrict__ gpad, const float *__restrict__ apad, const int *__restrict__ koff,
+                     float *__restrict__ part, int B, int L, int H, int W, int p, int Wp, int plane, int WpG, int gplane,
+                     int ncb, int nsl, int tiles_per_slice, int tiles_per_row)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pl = lane & 31, h = lane >> 5;
+    const long long unit = (long long)blockIdx.x * kWavesPerGroup + wave;
+    if (unit >= (long long)ncb * nsl) return;
+    const int cb = (int)(unit % ncb), sl = (int)(unit / ncb);
+    const long long ntiles = (long long)B * H * tiles_per_row;
+    const long long t0 = (long long)sl * tiles_per_slice;
+    const long long t1 = t0 + tiles_per_slice < ntiles ? t0 + tiles_per_slice : ntiles;
+    const int coff = koff[cb * 32 + pl];                 // this lane's column: plane and tap offset in the activation planes
+    const bool row_ok = pl < L;
+    f16v d[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) d[m][v] = 0.f;
+    for (long long tile = t0; tile < t1; ++tile) {
+        const int tx = (int)(tile % tiles_per_row);
+        const long long ry = tile / tiles_per_row;
+        const int y = (int)(ry % H), b = (int)(ry / H);
+        const int x = tx * 64 + 32 * h;
+        const float *arow = apad + (size_t)b * L * plane + (size_t)y * Wp + x + coff;
+        const float *grow = gpad + ((size_t)b * L * M + (row_ok ? pl : 0)) * gplane + (size_t)(y + p) * WpG + x + p;
+#pragma unroll 2
+        for (int j = 0; j < 32; j += 4) {
+            const f4u bv = *reinterpret_cast<const f4u *>(arow + j);
+            f4u av[M];
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                av[m] = *reinterpret_cast<const f4u *>(grow + (size_t)m * L * gplane + j);
+                if (!row_ok) av[m] = f4u{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int m = 0; m < M; ++m) d[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][q], bv[q], d[m], 0, 0, 0);
+        }
+    }
+    // register v of lane (p, h): row 8 (v/4) + 4 h + v%4, column p
+    float *out = part + ((size_t)sl * ncb + cb) * (size_t)(M * 1024);
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) out[m * 1024 + (8 * (v / 4) + 4 * h + (v % 4)) * 32 + pl] = d[m][v];
+}
+
+// d conv_w[m*L + l][kk] = sum over the slices (in order) of part[slice][kk / 32][m][l][kk % 32]
+__global__ void __launch_bounds__(256)
+context_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ d_conv_w, int L, int M, int KK, int ncb, int nsl)
+{
+    const size_t n = (size_t)L * M * KK;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int kk = (int)(idx % KK), oc = (int)(idx / KK);
+    const int m = oc / L, l = oc - m * L;
+    const size_t at = ((size_t)(kk >> 5) * M + m) * 1024 + l * 32 + (kk & 31);
+    float s = 0.f;
+    for (int sl = 0; sl < nsl; ++sl) s += part[(size_t)sl * ncb * (M * 1024) + at];
+    d_conv_w[idx] = s;
+}
+
 struct ContextWorkspace {
     size_t apad, w2, koff, total;
     int Hp, Wp, KK, KKp;
+    // backward only
+    size_t logq, amin, cmin, gpad, wt, koff2, da, part;
+    int HpG, WpG, KK2, KK2p, ncb, nsl, tiles_per_slice;
 };
 
-ContextWorkspace context_carve(int B, int L, int M, int H, int W, int ks)
+constexpr int kWgradWaves = 6144;     // waves of the weight-gradient launch (column blocks x pixel slices)
+
+ContextWorkspace context_carve(int B, int L, int M, int H, int W, int ks, bool backward = false)
 {
     ContextWorkspace w{};
     w.Hp = H + ks - 1;
@@ -226,31 +457,92 @@ ContextWorkspace context_carve(int B, int L, int M, int H, int W, int ks)
     w.KKp = (w.KK + kChunk - 1) / kChunk * kChunk;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    w.apad = take(((size_t)B * L * w.Hp * w.Wp + 64) * 4);
+    w.apad = take(((size_t)B * L * w.Hp * w.Wp + 128) * 4);
     w.w2 = take((size_t)w.KKp * 32 * M * 4);
     w.koff = take((size_t)w.KKp * 4);
+    if (backward) {
+        const size_t n = (size_t)B * L * H * W;
+        w.logq = take(n * 4);
+        w.amin = take(n);
+        w.cmin = take(n * 4);
+        w.HpG = H + ks - 1;
+        w.WpG = (W + 63) / 64 * 64 + ks - 1;           // the last 64-pixel tile of a row ends inside the zero padding
+        w.gpad = take(((size_t)B * L * M * w.HpG * w.WpG + 128) * 4);
+        w.KK2 = L * M * ks * ks;
+        w.KK2p = (w.KK2 + kChunk - 1) / kChunk * kChunk;
+        w.wt = take((size_t)w.KK2p * 32 * 4);
+        w.koff2 = take((size_t)w.KK2p * 4);
+        w.da = take(n * 4);
+        w.ncb = w.KKp / 32;
+        const long long ntiles = (long long)B * H * ((W + 63) / 64);
+        long long nsl = kWgradWaves / w.ncb;
+        if (nsl < 1) nsl = 1;
+        if (nsl > ntiles) nsl = ntiles;
+        w.tiles_per_slice = (int)((ntiles + nsl - 1) / nsl);
+        w.nsl = (int)((ntiles + w.tiles_per_slice - 1) / w.tiles_per_slice);
+        w.part = take((size_t)w.nsl * w.ncb * M * 1024 * 4);
+    }
     w.total = off;
     return w;
 }
 
 bool context_supported(int L, int M, int ks) { return L >= 1 && L <= 32 && M >= 1 && M <= 5 && ks >= 1 && ks <= 15 && (ks & 1); }
 
-template <int M>
-int launch(const ContextWorkspace &ws, char *base, const float *conv_b, const float *ga_w, const float *ga_b, const float *unary,
-           float *smooth, float *logq, int B, int L, int H, int W, hipStream_t st)
+// Launch of the implicit-GEMM kernel: the forward (MODE 0) or a plain convolution into `smooth` (MODE 1, M = 1).
+template <int M, int MODE>
+int launch(const float *planes, const float *w2, const int *koff, int KKp, int Cin, int Wp, int plane, const float *conv_b,
+           const float *ga_w, const float *ga_b, const float *unary, float *smooth, float *logq, unsigned char *amin, float *cmin,
+           int B, int L, int H, int W, hipStream_t st)
 {
     const int tiles_per_row = (W + 31) / 32;
     const long long ntiles = (long long)B * H * tiles_per_row;
     const long long groups = (ntiles + kWavesPerGroup * kTilesPerWave - 1) / (kWavesPerGroup * kTilesPerWave);
     if (groups >= (1LL << 31)) return MFL_ERR_TOO_LARGE;
-    const size_t lds = (size_t)kChunk * 32 * M * 4 + (size_t)ws.KKp * 4;
+    const size_t lds = (size_t)kChunk * 32 * M * 4 + (size_t)KKp * 4;
     if (lds > 160 * 1024) return MFL_ERR_INVALID_ARGUMENT;
     // (the attribute belongs to the current device's copy of the kernel: set before every launch)
-    MFL_CHECK_HIP(hipFuncSetAttribute((const void *)label_context_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(label_context_kernel<M>, dim3((unsigned)groups), dim3(64 * kWavesPerGroup), lds, st,
-                       (const float *)(base + ws.apad), (const float *)(base + ws.w2), (const int *)(base + ws.koff), conv_b, ga_w, ga_b,
-                       unary, smooth, logq, B, L, H, W, ws.Wp, ws.Hp * ws.Wp, ws.KKp, tiles_per_row);
+    MFL_CHECK_HIP(hipFuncSetAttribute((const void *)label_context_kernel<M, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL((label_context_kernel<M, MODE>), dim3((unsigned)groups), dim3(64 * kWavesPerGroup), lds, st, planes, w2, koff,
+                       conv_b, ga_w, ga_b, unary, smooth, logq, amin, cmin, B, L, Cin, H, W, Wp, plane, KKp, tiles_per_row);
     return (int)hipGetLastError();
+}
+
+// The forward on a carved workspace: activations into padded planes, weights permuted, fused kernel.
+int context_forward(const ContextWorkspace &ws, char *base, const float *t, const float *la_w, const float *la_b, const float *conv_w,
+                    const float *conv_b, const float *ga_w, const float *ga_b, const float *unary, float *smooth, float *logq,
+                    unsigned char *amin, float *cmin, int B, int L, int M, int H, int W, int ks, hipStream_t st)
+{
+    float *apad = (float *)(base + ws.apad);
+    const size_t npad = (size_t)B * L * ws.Hp * ws.Wp + 128;
+    MFL_CHECK_HIP(hipMemsetAsync(apad, 0, npad * 4, st));
+    const size_t n = (size_t)B * L * H * W;
+    const unsigned g1 = (unsigned)((n + 255) / 256 < 65535u * 8u ? (n + 255) / 256 : 65535u * 8u);
+    hipLaunchKernelGGL(label_context_activation_kernel, dim3(g1), dim3(256), 0, st, t, la_w, la_b, apad, B, L, H, W, ws.Hp, ws.Wp,
+                       ks / 2);
+    const size_t nw = (size_t)ws.KKp * 32 * M;
+    hipLaunchKernelGGL(label_context_weights_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, conv_w,
+                       (float *)(base + ws.w2), (int *)(base + ws.koff), L, M, ks, ws.KK, ws.KKp, ws.Hp * ws.Wp, ws.Wp);
+    MFL_CHECK_HIP(hipGetLastError());
+    const float *w2 = (const float *)(base + ws.w2);
+    const int *koff = (const int *)(base + ws.koff);
+    const int plane = ws.Hp * ws.Wp;
+#define MFL_CTX_FWD(MV) \
+    case MV: return launch<MV, 0>(apad, w2, koff, ws.KKp, L, ws.Wp, plane, conv_b, ga_w, ga_b, unary, smooth, logq, amin, cmin, B, L, H, W, st);
+    switch (M) {
+        MFL_CTX_FWD(1) MFL_CTX_FWD(2) MFL_CTX_FWD(3) MFL_CTX_FWD(4) MFL_CTX_FWD(5)
+    default: return MFL_ERR_INVALID_ARGUMENT;
+    }
+#undef MFL_CTX_FWD
+}
+
+template <int M>
+void launch_wgrad(const ContextWorkspace &ws, char *base, int B, int L, int H, int W, int ks, hipStream_t st)
+{
+    const long long units = (long long)ws.ncb * ws.nsl;
+    hipLaunchKernelGGL(context_wgrad_kernel<M>, dim3((unsigned)((units + kWavesPerGroup - 1) / kWavesPerGroup)), dim3(64 * kWavesPerGroup), 0,
+                       st, (const float *)(base + ws.gpad), (const float *)(base + ws.apad), (const int *)(base + ws.koff),
+                       (float *)(base + ws.part), B, L, H, W, ks / 2, ws.Wp, ws.Hp * ws.Wp, ws.WpG, ws.HpG * ws.WpG, ws.ncb, ws.nsl,
+                       ws.tiles_per_slice, (W + 63) / 64);
 }
 
 }  // namespace
@@ -264,11 +556,23 @@ size_t label_context_workspace_bytes(int B, int L, int M, int H, int W, int ks)
     return context_carve(B, L, M, H, W, ks).total;
 }
 
+size_t label_context_backward_workspace_bytes(int B, int L, int M, int H, int W, int ks)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || !context_supported(L, M, ks)) return 0;
+    if ((long long)B * L * M * (H + ks - 1) * ((W + 63) / 64 * 64 + ks - 1) >= (1LL << 31)) return 0;
+    return context_carve(B, L, M, H, W, ks, true).total;
+}
+
 }  // namespace mfl
 
 extern "C" size_t mfl_label_context_workspace_bytes(int B, int L, int M, int H, int W, int ks)
 {
     return mfl::label_context_workspace_bytes(B, L, M, H, W, ks);
+}
+
+extern "C" size_t mfl_label_context_backward_workspace_bytes(int B, int L, int M, int H, int W, int ks)
+{
+    return mfl::label_context_backward_workspace_bytes(B, L, M, H, W, ks);
 }
 
 extern "C" int mfl_label_context_forward(const float *t, const float *la_w, const float *la_b, const float *conv_w,
@@ -282,25 +586,73 @@ extern "C" int mfl_label_context_forward(const float *t, const float *la_w, cons
     if ((long long)B * L * (H + ks - 1) * (W + ks - 1) >= (1LL << 31)) return MFL_ERR_TOO_LARGE;
     const ContextWorkspace ws = context_carve(B, L, M, H, W, ks);
     if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
+    return context_forward(ws, (char *)workspace, t, la_w, la_b, conv_w, conv_b, ga_w, ga_b, unary, smooth, logq, nullptr, nullptr, B, L,
+                           M, H, W, ks, (hipStream_t)stream);
+}
+
+extern "C" int mfl_label_context_backward(const float *t, const float *la_w, const float *la_b, const float *conv_w,
+                                          const float *conv_b, const float *ga_w, const float *ga_b, const float *unary,
+                                          const float *grad_logq, const float *grad_smooth, float *d_t, float *d_unary,
+                                          float *d_la_w, float *d_la_b, float *d_conv_w, float *d_conv_b, float *d_ga_w,
+                                          float *d_ga_b, int B, int L, int M, int H, int W, int ks, void *workspace,
+                                          size_t workspace_bytes, mfl_stream_t stream)
+{
+    if (!t || !conv_w || !unary || (!grad_logq && !grad_smooth) || !d_t || !d_unary || !d_conv_w) return MFL_ERR_INVALID_ARGUMENT;
+    if ((la_w == nullptr) != (la_b == nullptr) || (ga_w == nullptr) != (ga_b == nullptr)) return MFL_ERR_INVALID_ARGUMENT;
+    if ((la_w != nullptr) != (d_la_w != nullptr) || (la_w != nullptr) != (d_la_b != nullptr)) return MFL_ERR_INVALID_ARGUMENT;
+    if ((ga_w != nullptr) != (d_ga_w != nullptr) || (ga_w != nullptr) != (d_ga_b != nullptr)) return MFL_ERR_INVALID_ARGUMENT;
+    if ((conv_b != nullptr) != (d_conv_b != nullptr)) return MFL_ERR_INVALID_ARGUMENT;
+    if (B <= 0 || H <= 0 || W <= 0 || !context_supported(L, M, ks)) return MFL_ERR_INVALID_ARGUMENT;
+    if (mfl::label_context_backward_workspace_bytes(B, L, M, H, W, ks) == 0) return MFL_ERR_TOO_LARGE;
+    const ContextWorkspace ws = context_carve(B, L, M, H, W, ks, true);
+    if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
     char *base = (char *)workspace;
     hipStream_t st = (hipStream_t)stream;
-    float *apad = (float *)(base + ws.apad);
-    const size_t npad = (size_t)B * L * ws.Hp * ws.Wp + 64;
-    MFL_CHECK_HIP(hipMemsetAsync(apad, 0, npad * 4, st));
-    const size_t n = (size_t)B * L * H * W;
-    const unsigned g1 = (unsigned)((n + 255) / 256 < 65535u * 8u ? (n + 255) / 256 : 65535u * 8u);
-    hipLaunchKernelGGL(label_context_activation_kernel, dim3(g1), dim3(256), 0, st, t, la_w, la_b, apad, B, L, H, W, ws.Hp, ws.Wp,
-                       ks / 2);
-    const size_t nw = (size_t)ws.KKp * 32 * M;
-    hipLaunchKernelGGL(label_context_weights_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, conv_w,
-                       (float *)(base + ws.w2), (int *)(base + ws.koff), L, M, ks, ws.KK, ws.KKp, ws.Hp * ws.Wp, ws.Wp);
-    MFL_CHECK_HIP(hipGetLastError());
-    switch (M) {
-    case 1: return launch<1>(ws, base, conv_b, ga_w, ga_b, unary, smooth, logq, B, L, H, W, st);
-    case 2: return launch<2>(ws, base, conv_b, ga_w, ga_b, unary, smooth, logq, B, L, H, W, st);
-    case 3: return launch<3>(ws, base, conv_b, ga_w, ga_b, unary, smooth, logq, B, L, H, W, st);
-    case 4: return launch<4>(ws, base, conv_b, ga_w, ga_b, unary, smooth, logq, B, L, H, W, st);
-    case 5: return launch<5>(ws, base, conv_b, ga_w, ga_b, unary, smooth, logq, B, L, H, W, st);
-    default: return MFL_ERR_INVALID_ARGUMENT;
+    const int HW = H * W, p = ks / 2, LM = L * M;
+    const size_t gplane = (size_t)ws.HpG * ws.WpG;
+    float *logq = (float *)(base + ws.logq), *cmin = (float *)(base + ws.cmin), *gpad = (float *)(base + ws.gpad);
+    float *da = (float *)(base + ws.da);
+    unsigned char *amin = (unsigned char *)(base + ws.amin);
+    // the forward again, keeping the arg-min mixture and the convolution's value there
+    int rc = context_forward(ws, base, t, la_w, la_b, conv_w, conv_b, ga_w, ga_b, unary, nullptr, logq, amin, cmin, B, L, M, H, W, ks, st);
+    if (rc) return rc;
+    MFL_CHECK_HIP(hipMemsetAsync(gpad, 0, ((size_t)B * LM * gplane + 128) * 4, st));
+    if (ga_w) {
+        MFL_CHECK_HIP(hipMemsetAsync(d_ga_w, 0, (size_t)LM * HW * 4, st));
+        MFL_CHECK_HIP(hipMemsetAsync(d_ga_b, 0, (size_t)LM * HW * 4, st));
     }
+    hipLaunchKernelGGL(context_pre_kernel, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, st, grad_logq, grad_smooth, (const float *)logq,
+                       unary, (const unsigned char *)amin, (const float *)cmin, ga_w, gpad, d_unary, d_ga_w, d_ga_b, B, L, M, H, W, ws.HpG,
+                       ws.WpG, p);
+    if (d_conv_b)
+        hipLaunchKernelGGL(context_bias_grad_kernel, dim3((unsigned)LM), dim3(256), 0, st, (const float *)gpad, d_conv_b, B, LM, gplane);
+    // data gradient: one block of 32 rows over the L*M gradient planes
+    {
+        const size_t nw = (size_t)ws.KK2p * 32;
+        hipLaunchKernelGGL(context_dgrad_weights_kernel, dim3((unsigned)((nw + 255) / 256 < 65535u ? (nw + 255) / 256 : 65535u)), dim3(256), 0, st,
+                           conv_w, (float *)(base + ws.wt), (int *)(base + ws.koff2), L, LM, ks, ws.KK2, ws.KK2p, (int)gplane, ws.WpG);
+        MFL_CHECK_HIP(hipGetLastError());
+        rc = launch<1, 1>(gpad, (const float *)(base + ws.wt), (const int *)(base + ws.koff2), ws.KK2p, LM, ws.WpG, (int)gplane, nullptr,
+                          nullptr, nullptr, nullptr, la_w ? da : d_t, nullptr, nullptr, nullptr, B, L, H, W, st);
+        if (rc) return rc;
+        if (la_w) {
+            const size_t LHW = (size_t)L * HW;
+            hipLaunchKernelGGL(context_affine_grad_kernel, dim3((unsigned)((LHW + 255) / 256)), dim3(256), 0, st, (const float *)da, t, la_w,
+                               d_t, d_la_w, d_la_b, B, LHW);
+        }
+    }
+    // weight gradient
+    switch (M) {
+    case 1: launch_wgrad<1>(ws, base, B, L, H, W, ks, st); break;
+    case 2: launch_wgrad<2>(ws, base, B, L, H, W, ks, st); break;
+    case 3: launch_wgrad<3>(ws, base, B, L, H, W, ks, st); break;
+    case 4: launch_wgrad<4>(ws, base, B, L, H, W, ks, st); break;
+    default: launch_wgrad<5>(ws, base, B, L, H, W, ks, st); break;
+    }
+    {
+        const size_t n = (size_t)LM * ws.KK;
+        hipLaunchKernelGGL(context_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float *)(base + ws.part),
+                           d_conv_w, L, M, ws.KK, ws.ncb, ws.nsl);
+    }
+    return (int)hipGetLastError();
 }

@@ -110,11 +110,34 @@ class MeanFieldLocal(nn.Module):
         return logq
 
 
+class _LabelContextFunction(torch.autograd.Function):
+    """(logq, smooth) = the fused label-context kernel; backward by mfl_label_context_backward (the forward is
+    recomputed there, so nothing but the inputs is kept)."""
+
+    @staticmethod
+    def forward(ctx, t, unary, la_w, la_b, conv_w, conv_b, ga_w, ga_b):
+        ctx.save_for_backward(t, unary, la_w, la_b, conv_w, conv_b, ga_w, ga_b)
+        logq, smooth = ops.label_context_forward(t, conv_w, unary, conv_b=conv_b, la_w=la_w, la_b=la_b, ga_w=ga_w, ga_b=ga_b,
+                                                 want_smooth=True)
+        return logq, smooth
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_logq, grad_smooth):
+        t, unary, la_w, la_b, conv_w, conv_b, ga_w, ga_b = ctx.saved_tensors
+        # an output nobody used arrives as zeros (materialised): passing it along costs one more read per element
+        g = ops.label_context_backward(t, conv_w, unary, grad_logq=grad_logq, grad_smooth=grad_smooth, conv_b=conv_b,
+                                       la_w=la_w, la_b=la_b, ga_w=ga_w, ga_b=ga_b)
+        order = ("d_t", "d_unary", "d_la_w", "d_la_b", "d_conv_w", "d_conv_b", "d_ga_w", "d_ga_b")
+        return tuple(g[key] if ctx.needs_input_grad[i] else None for i, key in enumerate(order))
+
+
 class LabelContext(nn.Module):
     """The reference's label-context block and combine step (DPNModel.forward phases 3-4, AdvancedModel.py:223,
     232-244) on the library's fused kernel.  Submodule names and parameter shapes are the reference's
     (AdvancedModel.py:138, 143-145), so the matching entries of a DPNModel state dict load here.
-    Inference only: the kernel has no backward."""
+    Under autograd the gradients of both outputs (the log-marginals and, for phase 3, the smoothness term,
+    AdvancedModel.py:237-238) come from the library's backward."""
 
     def __init__(self, in_height: int, in_width: int, num_labels: int = 21, num_mixture_filters: int = 5,
                  kernel_size: int = 9):
@@ -127,10 +150,14 @@ class LabelContext(nn.Module):
         self.global_activation_function = LinearActivation(channels, in_height, in_width)
 
     def forward(self, local_output: torch.Tensor, unary: torch.Tensor, want_smooth: bool = False):
+        conv = self.global_convolution_layer
         if torch.is_grad_enabled() and (local_output.requires_grad or unary.requires_grad
                                         or any(p.requires_grad for p in self.parameters())):
-            raise RuntimeError("LabelContext runs without gradients (wrap the call in torch.no_grad())")
-        conv = self.global_convolution_layer
+            logq, smooth = _LabelContextFunction.apply(local_output, unary, self.local_activation_function.weight,
+                                                       self.local_activation_function.bias, conv.weight, conv.bias,
+                                                       self.global_activation_function.weight,
+                                                       self.global_activation_function.bias)
+            return (logq, smooth) if want_smooth else logq
         return ops.label_context_forward(local_output, conv.weight, unary, conv_b=conv.bias,
                                          la_w=self.local_activation_function.weight,
                                          la_b=self.local_activation_function.bias,

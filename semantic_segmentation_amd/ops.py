@@ -204,6 +204,45 @@ def label_context_forward(t, conv_w, unary, conv_b=None, la_w=None, la_b=None, g
     return (logq, smooth) if want_smooth else logq
 
 
+def label_context_backward(t, conv_w, unary, grad_logq=None, grad_smooth=None, conv_b=None, la_w=None, la_b=None,
+                           ga_w=None, ga_b=None):
+    """Gradients of label_context_forward (autograd through AdvancedModel.py:223, 232-244; loss.backward(),
+    AdvancedModel.py:299) for dL/dlogq and / or dL/dsmooth.  Returns a dict with d_t, d_unary, d_conv_w and, for the
+    optional inputs that were given, d_conv_b, d_la_w, d_la_b, d_ga_w, d_ga_b (shaped like the inputs)."""
+    _lib.require_device(t, conv_w, unary, grad_logq, grad_smooth, conv_b, la_w, la_b, ga_w, ga_b)
+    t, conv_w, unary, conv_b = _c(t), _c(conv_w), _c(unary), _c(conv_b)
+    la_w, la_b, ga_w, ga_b, grad_logq, grad_smooth = _c(la_w), _c(la_b), _c(ga_w), _c(ga_b), _c(grad_logq), _c(grad_smooth)
+    B, L, H, W = t.shape
+    if conv_w.dim() != 4 or conv_w.shape[1] != L or conv_w.shape[2] != conv_w.shape[3] or conv_w.shape[0] % L:
+        raise RuntimeError(f"conv_w must be [L*M, {L}, ks, ks], got {tuple(conv_w.shape)}")
+    M, ks = conv_w.shape[0] // L, conv_w.shape[2]
+    if grad_logq is None and grad_smooth is None:
+        raise ValueError("a gradient of logq or of smooth is needed")
+    for g in (grad_logq, grad_smooth, unary):
+        if g is not None and g.shape != t.shape:
+            raise RuntimeError(f"expected {tuple(t.shape)}, got {tuple(g.shape)}")
+    if (la_w is None) != (la_b is None) or (ga_w is None) != (ga_b is None):
+        raise ValueError("affine weight and bias must be given together")
+    if la_w is not None and (la_w.numel() != L * H * W or la_b.numel() != L * H * W):
+        raise RuntimeError("la_w / la_b must hold L*H*W elements")
+    if ga_w is not None and (ga_w.numel() != L * M * H * W or ga_b.numel() != L * M * H * W):
+        raise RuntimeError("ga_w / ga_b must hold L*M*H*W elements")
+    n = int(lib.mfl_label_context_backward_workspace_bytes(B, L, M, H, W, ks))
+    if n == 0:
+        raise ValueError(f"unsupported label-context problem: L={L} (<= 32), M={M} (<= 5), ks={ks} (odd, <= 15), or too large")
+    like = lambda v: None if v is None else torch.empty_like(v)
+    out = {"d_t": torch.empty_like(t), "d_unary": torch.empty_like(t), "d_conv_w": torch.empty_like(conv_w),
+           "d_conv_b": like(conv_b), "d_la_w": like(la_w), "d_la_b": like(la_b), "d_ga_w": like(ga_w), "d_ga_b": like(ga_b)}
+    with torch.cuda.device(t.device):
+        ws = torch.empty(n, dtype=torch.uint8, device=t.device)
+        _lib.check(lib.mfl_label_context_backward(
+            ptr(t), ptr(la_w), ptr(la_b), ptr(conv_w), ptr(conv_b), ptr(ga_w), ptr(ga_b), ptr(unary), ptr(grad_logq),
+            ptr(grad_smooth), ptr(out["d_t"]), ptr(out["d_unary"]), ptr(out["d_la_w"]), ptr(out["d_la_b"]), ptr(out["d_conv_w"]),
+            ptr(out["d_conv_b"]), ptr(out["d_ga_w"]), ptr(out["d_ga_b"]), B, L, M, H, W, ks, ptr(ws), n, stream_of(t)),
+            "mfl_label_context_backward")
+    return out
+
+
 def iou_counts(pred: torch.Tensor, target: torch.Tensor, num_labels: int) -> torch.Tensor:
     """int64 [3, num_labels]: per class the pixels in both, in the prediction, in the target
     (the counts behind DPNModel.calc_intersection_over_union, AdvancedModel.py:448-485).

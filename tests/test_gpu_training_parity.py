@@ -180,3 +180,96 @@ def test_strict_marginal_figure_on_the_stress_golden(S):
         mine = strict_rel_err_on_marginals(lq, d[f"logq64_it{it}"])
         reference_fp32 = strict_rel_err_on_marginals(d[f"logq_it{it}"], d[f"logq64_it{it}"])
         assert mine < max(1e-4, 2 * reference_fp32), (it, mine, reference_fp32)
+
+
+# ------------------------------------------------------------------ label-context backward
+_CTX_KEYS = (("d_t", "dt"), ("d_unary", "dunary"), ("d_la_w", "dla_w"), ("d_la_b", "dla_b"), ("d_conv_w", "dconv_w"),
+             ("d_conv_b", "dconv_b"), ("d_ga_w", "dga_w"), ("d_ga_b", "dga_b"))
+
+
+@pytest.mark.parametrize("path", golden_files("tailgrad"))
+def test_label_context_backward_golden(path, S):
+    """mfl_label_context_backward against the reference modules' autograd gradients through
+    LinearActivation -> Conv2d -> LinearActivation -> BlockMinPooling -> combine -> LogSoftmax
+    (AdvancedModel.py:223-244, 299; tests/golden/make_golden.py: gen_tail_grad), at 1e-4."""
+    d = load(path)
+    g = S.ops.label_context_backward(dev(d["t"]), dev(d["conv_w"]), dev(d["unary"]), grad_logq=dev(d["G"]), conv_b=dev(d["conv_b"]),
+                                     la_w=dev(d["la_w"]), la_b=dev(d["la_b"]), ga_w=dev(d["ga_w"]), ga_b=dev(d["ga_b"]))
+    for mine, key in _CTX_KEYS:
+        assert_close(host(g[mine]).reshape(d[key + "64"].shape), d[key + "64"], RTOL, key)
+
+
+def test_dpn_phase_3_and_4_gradients_on_the_library_alone(S):
+    """Training phases 3 and 4 of DPNModel (AdvancedModel.py:198-244, 364-381) with the unary bypassed: Conv2dLocal and
+    LabelContext under autograd against the gradients of the imported DPNModel (the model's own 50x50 window)."""
+    d = load(golden_files("dpngrad")[0])
+    B, L, H, W = d["unary"].shape
+    k, M = int(d["k"]), int(d["mixtures"])
+    local = S.Conv2dLocal(H, W, L, (k, k)).cuda()
+    ctx = S.LabelContext(H, W, num_labels=L, num_mixture_filters=M, kernel_size=int(d["ks"])).cuda()
+    with torch.no_grad():
+        local.position_weight.fill_(float(d["pw"]))
+        local.color_weight.fill_(float(d["cw"]))
+        ctx.local_activation_function.weight.copy_(dev(d["la_w"]))
+        ctx.local_activation_function.bias.copy_(dev(d["la_b"]))
+        ctx.global_convolution_layer.weight.copy_(dev(d["conv_w"]))
+        ctx.global_convolution_layer.bias.copy_(dev(d["conv_b"]))
+        ctx.global_activation_function.weight.copy_(dev(d["ga_w"]))
+        ctx.global_activation_function.bias.copy_(dev(d["ga_b"]))
+    names = {"dpw": local.position_weight, "dcw": local.color_weight, "dla_w": ctx.local_activation_function.weight,
+             "dla_b": ctx.local_activation_function.bias, "dconv_w": ctx.global_convolution_layer.weight,
+             "dconv_b": ctx.global_convolution_layer.bias, "dga_w": ctx.global_activation_function.weight,
+             "dga_b": ctx.global_activation_function.bias}
+    handle = S.ColorDistanceHandle(dev(d["img"]), (k, k))
+    for phase in (3, 4):
+        for p in names.values():
+            p.grad = None
+        U = dev(d["unary"]).requires_grad_(True)
+        logq, smooth = ctx(local(U, handle), U, want_smooth=True)
+        out = torch.log_softmax(smooth, dim=1) if phase == 3 else logq            # AdvancedModel.py:237-238 / 242-244
+        assert_close(host(out), d[f"out_p{phase}"], RTOL, f"phase {phase} output")
+        (out * dev(d["G"])).sum().backward()
+        assert_close(host(U.grad), d[f"dunary_p{phase}"], RTOL, f"phase {phase} d unary")
+        for key, p in names.items():
+            want = d[f"{key}_p{phase}"]
+            if key in ("dpw", "dcw"):
+                assert abs(float(p.grad) - float(want[0])) <= 2e-4 * abs(float(want[0])), (phase, key, float(p.grad), float(want[0]))
+            else:
+                assert_close(host(p.grad), want, RTOL, f"phase {phase} {key}")
+
+
+@pytest.mark.parametrize("B,L,M,H,W,ks", [(2, 21, 5, 40, 70, 9), (1, 7, 2, 33, 31, 3), (3, 32, 1, 20, 65, 5), (1, 19, 4, 70, 130, 7)])
+def test_label_context_backward_vs_float64_autograd(B, L, M, H, W, ks, S):
+    """The library's backward against float64 autograd of the same chain composed from stock torch ops on the host, on
+    sizes with ragged row tiles (image rows that end inside a 64-pixel tile of the weight gradient), with and without
+    the optional affines and bias; and bit-for-bit equal between two runs (every sum has a fixed order)."""
+    g = torch.Generator().manual_seed(91)
+    t = torch.randn(B, L, H, W, generator=g)
+    unary = 2 * torch.randn(B, L, H, W, generator=g)
+    G = torch.randn(B, L, H, W, generator=g)
+    GS = 0.3 * torch.randn(B, L, H, W, generator=g)
+    conv_w = 0.05 * torch.randn(L * M, L, ks, ks, generator=g)
+    conv_b = 0.1 * torch.randn(L * M, generator=g)
+    la_w, la_b = 1 + 0.2 * torch.randn(1, L, H, W, generator=g), 0.1 * torch.randn(1, L, H, W, generator=g)
+    ga_w, ga_b = 1 + 0.2 * torch.randn(1, L * M, H, W, generator=g), 0.1 * torch.randn(1, L * M, H, W, generator=g)
+    for full in (True, False):
+        leaves = {"t": t, "unary": unary, "conv_w": conv_w}
+        if full:
+            leaves.update(conv_b=conv_b, la_w=la_w, la_b=la_b, ga_w=ga_w, ga_b=ga_b)
+        v = {n: x.double().clone().requires_grad_(True) for n, x in leaves.items()}
+        a = v["la_w"] * v["t"] + v["la_b"] if full else v["t"]
+        c = torch.nn.functional.conv2d(a, v["conv_w"], v["conv_b"] if full else None, padding=ks // 2)
+        if full:
+            c = v["ga_w"] * c + v["ga_b"]
+        smooth = c.reshape(B, M, L, H, W).min(dim=1).values
+        logq = torch.log_softmax(torch.log_softmax(v["unary"], dim=1) - smooth, dim=1)
+        ((logq * G.double()).sum() + (smooth * GS.double()).sum()).backward()
+        kw = {n: x.cuda() for n, x in leaves.items() if n not in ("t", "unary", "conv_w")}
+        run = lambda: S.ops.label_context_backward(t.cuda(), conv_w.cuda(), unary.cuda(), grad_logq=G.cuda(), grad_smooth=GS.cuda(), **kw)
+        got, again = run(), run()
+        for n in leaves:
+            key = "d_" + n
+            assert_close(host(got[key]), v[n].grad.numpy(), RTOL, f"{key} full={full}")
+            assert torch.equal(got[key], again[key]), f"{key}: two runs differ"
+        if not full:
+            assert all(got[key] is None for key in ("d_conv_b", "d_la_w", "d_la_b", "d_ga_w", "d_ga_b"))
