@@ -281,7 +281,10 @@ int pick_m(const Geom &g1, int cc, int max_m)
 struct Workspace {
     // carve-up of the caller's buffer; all offsets 256-byte aligned
     size_t xp, xp2, ip4, tab, dxd, dxp, partials, msg, total;
+    size_t psum, qsum, dxp64, consts, partials2;     // tap-split backward only
 };
+
+constexpr int kDiagBackwardBlocks = 2048;    // blocks (and partial sums) of the backward's finishing pass
 
 size_t padded_floats(const Geom &g) { return (size_t)g.B * g.C * g.plane + padded_slack(g); }
 
@@ -334,6 +337,14 @@ Workspace carve(int op, const Geom &g, int cc)
         w.dxd = take((size_t)g.B * g.C * g.L * 4);
         w.dxp = take(padded_floats(g) * 4);
         w.partials = take((size_t)backward_blocks(g, cc) * 2 * 4);
+        if (taps_kernel_applies(g)) {
+            // (with an image: the tap-split backward; dxd / dxp above serve the cd-tensor variant of the same shape)
+            w.psum = take((size_t)g.B * g.C * g.L * 4);
+            w.qsum = take((size_t)g.B * g.C * g.L * 4);
+            w.dxp64 = take(padded_floats(g) * 8);
+            w.consts = take(8 * 4);
+            w.partials2 = take((size_t)2 * kDiagBackwardBlocks * 4);
+        }
     }
     if (op == MFL_OP_MEANFIELD_FORWARD) {
         w.xp2 = take(padded_floats(g) * 4);
@@ -398,6 +409,14 @@ int dispatch_local_forward(int cc, const GatherArgs &a, float *y, hipStream_t st
 int dispatch_local_backward(int cc, const GatherArgs &a, const BackwardArgs &b, hipStream_t st)
 {
     MFL_BY_CC(cc, launch_local_backward, a, b, st)
+}
+#endif
+#if defined(MFL_DEV_CC) && defined(MFL_DEV_STEP_ONLY)
+int dispatch_local_backward_taps(int, const GatherArgs &, const TapsBackwardArgs &, hipStream_t) { return MFL_ERR_INVALID_ARGUMENT; }
+#else
+int dispatch_local_backward_taps(int cc, const GatherArgs &a, const TapsBackwardArgs &t, hipStream_t st)
+{
+    MFL_BY_CC(cc, launch_local_backward_taps, a, t, st)
 }
 #endif
 int dispatch_meanfield_step(int cc, const GatherArgs &a, const StepArgs &s, hipStream_t st)
@@ -471,8 +490,6 @@ struct DiagWorkspace {
     size_t xp, xp2, ip4, table, groups, compat, total;
     size_t psum, qsum, consts, partials;     // backward only
 };
-
-constexpr int kDiagBackwardBlocks = 2048;    // blocks (and partial sums) of the backward's finishing pass
 
 // c[0..3] = the weight pairs (1, 0), (0, 1) of the two plain window sums; c[6], c[7] = 0 (maxima, as bits)
 __global__ void diag_backward_consts_kernel(float *c)
@@ -1075,6 +1092,28 @@ int mfl_local_backward(const float *x, const float *img, const float *cd, const 
     hipStream_t st = (hipStream_t)stream;
     rc = launch_prepare(workspace, g, x, img, xp, ip4, tab, st);
     if (rc) return rc;
+    if (img && taps_kernel_applies(g)) {
+        // large windows on small images: the taps of a pixel split over threads, plain window sums P, Q and an
+        // order-free fixed-point scatter, then the finishing pass the diagonal backward uses
+        float *consts = (float *)(base + ws.consts), *P = (float *)(base + ws.psum), *Q = (float *)(base + ws.qsum);
+        unsigned long long *dxp64 = (unsigned long long *)(base + ws.dxp64);
+        float *partials2 = (float *)(base + ws.partials2);
+        const size_t n = (size_t)B * C * g.L;
+        hipLaunchKernelGGL(diag_backward_consts_kernel, dim3(1), dim3(64), 0, st, consts);
+        hipLaunchKernelGGL(diag_backward_absmax_kernel, dim3(grid_for(n) < 1024 ? grid_for(n) : 1024), dim3(kThreads), 0, st, dy, x, n, img,
+                           (size_t)B * 3 * g.L, consts);
+        hipLaunchKernelGGL(diag_backward_scale_kernel, dim3(1), dim3(64), 0, st, pos_w, col_w, k, consts);
+        MFL_CHECK_HIP(hipMemsetAsync(dxp64, 0, padded_floats(g) * 8, st));
+        const GatherArgs ga{g, false, false, xp, ip4, nullptr, tab, pos_w, col_w};
+        const TapsBackwardArgs ta{dy, consts + 4, P, Q, dxp64};
+        rc = dispatch_local_backward_taps(cc, ga, ta, st);
+        if (rc) return rc;
+        const int blocks = grid_for(n) < kDiagBackwardBlocks ? grid_for(n) : kDiagBackwardBlocks;
+        hipLaunchKernelGGL(diag_backward_finish_kernel, dim3(blocks), dim3(kThreads), 0, st, dy, x, P, Q, (const long long *)dxp64, consts,
+                           pos_w, col_w, dx, partials2, B * C, H, W, g.Hp, g.Wp, g.p0);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kThreads), 0, st, partials2, blocks, dparams);
+        return (int)hipGetLastError();
+    }
     MFL_CHECK_HIP(hipMemsetAsync(dxp, 0, padded_floats(g) * 4, st));
     const int nchunks = (g.C + cc - 1) / cc;
     if (dcd && nchunks > 1) MFL_CHECK_HIP(hipMemsetAsync(dcd, 0, (size_t)B * g.L * g.K * 4, st));

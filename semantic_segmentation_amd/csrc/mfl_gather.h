@@ -39,6 +39,14 @@ struct BackwardArgs {
     float *dxd, *dxp, *partials, *dcd;
 };
 
+// tap-split backward (local_backward_taps_kernel): plain window sums P, Q and the fixed-point gradient planes
+struct TapsBackwardArgs {
+    const float *dy;
+    const float *scale;             // the fixed-point scale (a power of two), device pointer
+    float *P, *Q;                   // [B][C][L]
+    unsigned long long *dxp;        // zeroed padded planes [B][C][Hp][Wp] of 64-bit sums
+};
+
 struct StepArgs {
     const float *unary, *aw, *ab, *compat;
     float *logq, *qp_out;
@@ -47,6 +55,7 @@ struct StepArgs {
 #define MFL_DECLARE_GATHER(CCV)                                                                            \
     int launch_local_forward_cc##CCV(const GatherArgs &a, float *y, hipStream_t st);                       \
     int launch_local_backward_cc##CCV(const GatherArgs &a, const BackwardArgs &b, hipStream_t st);         \
+    int launch_local_backward_taps_cc##CCV(const GatherArgs &a, const TapsBackwardArgs &t, hipStream_t st); \
     int launch_meanfield_step_cc##CCV(const GatherArgs &a, const StepArgs &s, hipStream_t st);
 
 MFL_DECLARE_GATHER(8)

@@ -30,6 +30,9 @@ __device__ __forceinline__ const int *stage_table(const int *__restrict__ tab_g,
     }
 }
 
+// tap-split kernels (large windows on small images): threads per pixel, pixels per workgroup
+constexpr int kTapSlices = 16, kTapPixels = kThreads / kTapSlices;
+
 #if MFL_KIND == 1
 // y[b][c][l] = x[b][c][l] * sum_t w[b][l][t] * S[b][c][l][t]
 // grid: (blocks_per_image, channel chunks, B)
@@ -83,8 +86,6 @@ local_forward_kernel(Geom g, const float *__restrict__ xp, const F4 *__restrict_
 // bound by that latency, and the few pixels leave most CUs idle.  Here the taps of a pixel are split over kTapSlices
 // threads (kTapPixels pixels per workgroup); the partial sums meet in LDS and are added in a fixed order.
 // Same index walk as window_sums (mfl_core.h) with one pixel per thread, started at the slice's first tap.
-constexpr int kTapSlices = 16, kTapPixels = kThreads / kTapSlices;
-
 template <int CC>
 __global__ void __launch_bounds__(kThreads)
 local_forward_taps_kernel(Geom g, const float *__restrict__ xp, const F4 *__restrict__ ip4, const int *__restrict__ tab,
@@ -394,6 +395,116 @@ local_backward_kernel(Geom g, const float *__restrict__ xp, const F4 *__restrict
     }
 }
 
+// Backward for large windows on small images (the reference model's own 50 x 50 window on 64 x 64, AdvancedModel.py:135-137):
+// the tap-split walk of local_forward_taps_kernel, transposed.  A pixel's taps are split over kTapSlices threads; each
+// keeps, per channel, the plain window sums with the weights pd[t] alone (P) and cd[l][t] alone (Q), which meet in LDS
+// and are added in a fixed order, and adds what its pixel sends to every element it reads, w[t] * dy * x, to the
+// gradient planes in 64-bit fixed point (integer atomics: the sums do not depend on the order).  dx and both parameter
+// gradients follow from P, Q and those planes (diag_backward_finish_kernel in mfl_api.hip):
+//   dx = dy * (pos_w * P + col_w * Q) + planes,  d pos_w = sum dy * x * P,  d col_w = sum dy * x * Q   (LocalConvolution.py:84-90)
+template <int CC>
+__global__ void __launch_bounds__(kThreads)
+local_backward_taps_kernel(Geom g, const float *__restrict__ xp, const F4 *__restrict__ ip4, const int *__restrict__ tab,
+                           const float *__restrict__ pos_w, const float *__restrict__ col_w, const float *__restrict__ dy,
+                           const float *__restrict__ scale, float *__restrict__ P, float *__restrict__ Q,
+                           unsigned long long *__restrict__ dxp)
+{
+    __shared__ float red[kTapSlices][CC][kTapPixels + 1];
+    const int tid = threadIdx.x, pxi = tid % kTapPixels, slice = tid / kTapPixels;
+    const int b = blockIdx.z, c0 = blockIdx.y * CC;
+    const int nch = min(CC, g.C - c0);
+    const int l_raw = blockIdx.x * kTapPixels + pxi;
+    const bool live = l_raw < g.L;
+    const int l = live ? l_raw : g.L - 1;
+    const int W = g.W, Wp = g.Wp, gap = Wp - W, CK = g.CK;
+    const int py = l / W, px = l - py * W;
+    const int ibase = py * Wp + px;
+    const float *xp_b = xp + (size_t)b * g.C * g.plane;
+    const F4 *ip_b = ip4 + (size_t)b * g.plane;
+    unsigned long long *dxp_b = dxp + (size_t)b * g.C * g.plane;
+    const float pw = *pos_w, cw = *col_w, fscale = *scale;
+    const int t0 = (int)((long long)g.K * slice / kTapSlices), t1 = (int)((long long)g.K * (slice + 1) / kTapSlices);
+    const long long f0 = ((long long)c0 * g.K + t0) * g.L + l;
+    const long long lp0 = f0 / CK;
+    int rs = (int)(f0 - lp0 * CK);
+    int xs = (int)(lp0 % W);
+    int ls = (int)(lp0 / W) * Wp + xs;
+    const int dq_lin = g.dqy * Wp + g.dqx, dK_lin = g.dKy * Wp + g.dKx;
+    const int ctr_off = g.p0 * Wp + g.p0;
+    float pacc[CC], qacc[CC], D[CC];
+#pragma unroll
+    for (int cc = 0; cc < CC; ++cc) {
+        pacc[cc] = 0.f;
+        qacc[cc] = 0.f;
+        D[cc] = (live && cc < nch) ? dy[((size_t)b * g.C + c0 + cc) * g.L + l] * xp_b[(size_t)(c0 + cc) * g.plane + ibase + ctr_off] : 0.f;
+    }
+    const F4 ctr = ip_b[ibase + ctr_off];
+    int ky = t0 / g.k, kx = t0 - ky * g.k;
+    for (int t = t0; t < t1; ++t) {
+        const F4 nb = ip_b[ibase + ky * Wp + kx];
+        const float d0 = ctr.x - nb.x, d1 = ctr.y - nb.y, d2 = ctr.z - nb.z;
+        const int dyy = ky - g.p0, dxx = kx - g.p0;
+        const float cd = d0 * d0 + d1 * d1 + d2 * d2, pd = (float)(dyy * dyy + dxx * dxx);
+        const float w = fmaf(cd, cw, pd * pw);
+        int r = rs, x = xs, lin = ls;
+        int a[CC];
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc) {
+            a[cc] = lin + tab[r];
+            if (cc >= nch) a[cc] = a[0];          // channels past the chunk: a valid dummy (their D is 0)
+            r += g.rhoK;
+            const int carry = r >= CK;
+            r -= carry ? CK : 0;
+            x += g.dKx + carry;
+            const int wrap = x >= W;
+            x -= wrap ? W : 0;
+            lin += dK_lin + carry + (wrap ? gap : 0);
+        }
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc) {
+            const float v = xp_b[a[cc]];
+            pacc[cc] = fmaf(pd, v, pacc[cc]);
+            qacc[cc] = fmaf(cd, v, qacc[cc]);
+            const float s = w * D[cc];
+            if (s != 0.f) fixed_point_add(dxp_b + a[cc], s, fscale);
+        }
+        rs += g.rho;
+        const int carry = rs >= CK;
+        rs -= carry ? CK : 0;
+        xs += g.dqx + carry;
+        const int wrap = xs >= W;
+        xs -= wrap ? W : 0;
+        ls += dq_lin + carry + (wrap ? gap : 0);
+        if (++kx == g.k) { kx = 0; ++ky; }
+    }
+    // the slices' partial sums meet in LDS and are added in slice order: P first, then Q through the same buffer
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) __syncthreads();
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc) red[slice][cc][pxi] = pass ? qacc[cc] : pacc[cc];
+        __syncthreads();
+        if (live) {
+            for (int cc = slice; cc < nch; cc += kTapSlices) {
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < kTapSlices; ++i) sum += red[i][cc][pxi];
+                (pass ? Q : P)[((size_t)b * g.C + c0 + cc) * g.L + l] = sum;
+            }
+        }
+    }
+}
+
+template <int CC>
+int launch_bwd_taps(const GatherArgs &a, const TapsBackwardArgs &t, hipStream_t st)
+{
+    const Geom &g = a.g;
+    const dim3 grid((g.L + kTapPixels - 1) / kTapPixels, (g.C + CC - 1) / CC, g.B);
+    hipLaunchKernelGGL((local_backward_taps_kernel<CC>), grid, dim3(kThreads), 0, st, g, a.xp, a.ip4, a.tab, a.pos_w, a.col_w, t.dy,
+                       t.scale, t.P, t.Q, t.dxp);
+    return (int)hipGetLastError();
+}
+
 #endif  // MFL_KIND == 2
 
 
@@ -497,6 +608,11 @@ int MFL_CAT(launch_local_backward_cc, MFL_CC)(const GatherArgs &a, const Backwar
     case 2: return launch_bwd<CC, 2, false, true>(a, b, st);
     }
     return MFL_ERR_INVALID_ARGUMENT;
+}
+
+int MFL_CAT(launch_local_backward_taps_cc, MFL_CC)(const GatherArgs &a, const TapsBackwardArgs &t, hipStream_t st)
+{
+    return launch_bwd_taps<MFL_CC>(a, t, st);
 }
 
 #endif  // MFL_KIND == 2

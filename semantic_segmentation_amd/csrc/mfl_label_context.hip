@@ -50,7 +50,11 @@ namespace {
 typedef float f16v __attribute__((ext_vector_type(16)));
 
 constexpr int kWavesPerGroup = 4;
-constexpr int kTilesPerWave = 1;    // (two tiles per wave, 160 accumulators: one wave per SIMD, 13.9 instead of 11.3 ms)
+// Tiles (32 pixels each) per wave: one for the fused forward (two tiles per wave, 160 accumulators, left one wave per SIMD:
+// 13.9 instead of 11.3 ms); four for the plain convolution of the data gradient, whose single block of rows would
+// otherwise issue one matrix instruction per weight read from LDS (15.1 ms with one tile per wave).
+template <int MODE>
+struct TilesPerWave { static constexpr int value = MODE == 1 ? 4 : 1; };
 constexpr int kChunk = 32;          // K-values of the weights per LDS stage (even)
 constexpr int kAhead = 4;           // k-steps whose activation loads are in flight together
 
@@ -109,6 +113,7 @@ label_context_kernel(const float *__restrict__ apad, const float *__restrict__ w
                      int W, int Wp, int plane, int KKp, int tiles_per_row)
 {
     constexpr int R = 32 * M;
+    constexpr int kTilesPerWave = TilesPerWave<MODE>::value;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *wl = lds;                                           // [kChunk][R]
     int *ko = reinterpret_cast<int *>(lds + kChunk * R);       // [KKp]
@@ -302,24 +307,32 @@ context_pre_kernel(const float *__restrict__ grad_logq, const float *__restrict_
 }
 
 // d conv_b[oc] = sum over images and pixels of the gradient planes (the padding adds zeros): one workgroup per
-// output channel, a fixed strided order per thread, then a fixed tree.
+// (output channel, image) sums a plane (a fixed strided order per thread, then a fixed tree) into part[b][oc];
+// the second kernel adds the images in order.
 __global__ void __launch_bounds__(256)
-context_bias_grad_kernel(const float *__restrict__ gpad, float *__restrict__ d_conv_b, int B, int LM, size_t gplane)
+context_bias_grad_kernel(const float *__restrict__ gpad, float *__restrict__ part, int LM, size_t gplane)
 {
     __shared__ float sh[256];
-    const int oc = blockIdx.x;
+    const int oc = blockIdx.x, b = blockIdx.y;
+    const float *pl = gpad + ((size_t)b * LM + oc) * gplane;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float *pl = gpad + ((size_t)b * LM + oc) * gplane;
-        for (size_t i = threadIdx.x; i < gplane; i += 256) s += pl[i];
-    }
+    for (size_t i = threadIdx.x; i < gplane; i += 256) s += pl[i];
     sh[threadIdx.x] = s;
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) d_conv_b[oc] = sh[0];
+    if (threadIdx.x == 0) part[(size_t)b * LM + oc] = sh[0];
+}
+
+__global__ void context_bias_grad_sum_kernel(const float *__restrict__ part, float *__restrict__ d_conv_b, int B, int LM)
+{
+    const int oc = blockIdx.x * blockDim.x + threadIdx.x;
+    if (oc >= LM) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += part[(size_t)b * LM + oc];
+    d_conv_b[oc] = s;
 }
 
 // Weights of the data gradient: d a = Conv2d(L*M -> L, ks x ks, pad ks/2) of the gradient planes with
@@ -480,7 +493,7 @@ ContextWorkspace context_carve(int B, int L, int M, int H, int W, int ks, bool b
         if (nsl > ntiles) nsl = ntiles;
         w.tiles_per_slice = (int)((ntiles + nsl - 1) / nsl);
         w.nsl = (int)((ntiles + w.tiles_per_slice - 1) / w.tiles_per_slice);
-        w.part = take((size_t)w.nsl * w.ncb * M * 1024 * 4);
+        w.part = take((size_t)w.nsl * w.ncb * M * 1024 * 4 + (size_t)B * L * M * 4);
     }
     w.total = off;
     return w;
@@ -496,6 +509,7 @@ int launch(const float *planes, const float *w2, const int *koff, int KKp, int C
 {
     const int tiles_per_row = (W + 31) / 32;
     const long long ntiles = (long long)B * H * tiles_per_row;
+    constexpr int kTilesPerWave = TilesPerWave<MODE>::value;
     const long long groups = (ntiles + kWavesPerGroup * kTilesPerWave - 1) / (kWavesPerGroup * kTilesPerWave);
     if (groups >= (1LL << 31)) return MFL_ERR_TOO_LARGE;
     const size_t lds = (size_t)kChunk * 32 * M * 4 + (size_t)KKp * 4;
@@ -624,8 +638,12 @@ extern "C" int mfl_label_context_backward(const float *t, const float *la_w, con
     hipLaunchKernelGGL(context_pre_kernel, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, st, grad_logq, grad_smooth, (const float *)logq,
                        unary, (const unsigned char *)amin, (const float *)cmin, ga_w, gpad, d_unary, d_ga_w, d_ga_b, B, L, M, H, W, ws.HpG,
                        ws.WpG, p);
-    if (d_conv_b)
-        hipLaunchKernelGGL(context_bias_grad_kernel, dim3((unsigned)LM), dim3(256), 0, st, (const float *)gpad, d_conv_b, B, LM, gplane);
+    if (d_conv_b) {
+        // (the per-image sums borrow the start of the weight gradient's partial-sum buffer, which is written later)
+        float *bpart = (float *)(base + ws.part);
+        hipLaunchKernelGGL(context_bias_grad_kernel, dim3((unsigned)LM, (unsigned)B), dim3(256), 0, st, (const float *)gpad, bpart, LM, gplane);
+        hipLaunchKernelGGL(context_bias_grad_sum_kernel, dim3((unsigned)((LM + 255) / 256)), dim3(256), 0, st, (const float *)bpart, d_conv_b, B, LM);
+    }
     // data gradient: one block of 32 rows over the L*M gradient planes
     {
         const size_t nw = (size_t)ws.KK2p * 32;

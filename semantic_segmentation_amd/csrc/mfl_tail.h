@@ -9,18 +9,6 @@
 
 namespace mfl {
 
-// Order-free accumulation of the backward scatter: a contribution v is added as the integer
-// round(v * scale) with a 64-bit integer atomic (integer sums do not depend on the order of the adds, so the
-// gradient is reproducible bit for bit; float atomics are not).  scale is a power of two chosen by the
-// host side so that |v * scale| < 2^50 for every contribution: 1.5 * 2^52 + v * scale is then exact in
-// double and its low mantissa bits are the rounded integer in two's complement.
-__device__ __forceinline__ void fixed_point_add(unsigned long long *p, float v, float scale)
-{
-    const double d = __builtin_fma((double)v, (double)scale, 6755399441055744.0);
-    const long long q = __builtin_bit_cast(long long, d) - 0x4338000000000000LL;
-    atomicAdd(p, (unsigned long long)q);
-}
-
 // The few pixels of a nearly empty last b-block (DiagGeom::tail_lanes) that the diagonal kernels
 // leave out, computed by extra workgroups at the end of the same launch (they fill the CUs that
 // the last round of regular workgroups leaves idle).  One wave per (image, group, chunk of 4 tail pixels); thread = (pixel, one of 16 channel

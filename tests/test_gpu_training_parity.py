@@ -273,3 +273,21 @@ def test_label_context_backward_vs_float64_autograd(B, L, M, H, W, ks, S):
             assert torch.equal(got[key], again[key]), f"{key}: two runs differ"
         if not full:
             assert all(got[key] is None for key in ("d_conv_b", "d_la_w", "d_la_b", "d_ga_w", "d_ga_b"))
+
+
+@pytest.mark.parametrize("shape", [(1, 21, 64, 64, 50), (2, 5, 40, 48, 20), (1, 32, 64, 64, 17), (1, 40, 30, 34, 16)])
+def test_large_window_backward_vs_oracle_and_bitwise_reproducible(shape, S, oracle):
+    """The backward on large windows over small images (the reference model's own 64 x 64 / 50 x 50 configuration,
+    AdvancedModel.py:135-137): the tap-split kernel with its fixed-order partial sums and fixed-point scatter, against
+    the C oracle and bit for bit equal between two runs."""
+    B, C, H, W, k = shape
+    x, img, dy = make_inputs(shape, 95)
+    for pw, cw in ((-0.004, -0.003), (0.3, -0.7)):
+        run = lambda: S.ops.local_backward(dev(x), scalar(pw), scalar(cw), k, dev(dy), image=dev(img))
+        dx, dpar, _ = run()
+        dx2, dpar2, _ = run()
+        assert torch.equal(dx, dx2) and torch.equal(dpar, dpar2)
+        rdx, rdpw, rdcw = oracle.local_backward(x, pw, cw, k, dy, img=img)
+        assert_close(host(dx), rdx, RTOL, "dx")
+        assert abs(float(dpar[0]) - rdpw) <= 2e-4 * abs(rdpw) + 1e-5, (float(dpar[0]), rdpw)
+        assert abs(float(dpar[1]) - rdcw) <= 2e-4 * abs(rdcw) + 1e-5, (float(dpar[1]), rdcw)

@@ -22,3 +22,12 @@ with torch.no_grad():
     ms = timed(f)
 flops = 2.0 * B * H * W * (L * M) * (L * ks * ks)
 print(f"label context B{B} L{L} M{M} {H}x{W} k{ks}: {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s (fp32 MFMA peak 157.3)")
+G = torch.randn(B, L, H, W, device="cuda", generator=g)
+conv = mod.global_convolution_layer
+bw = lambda: S.ops.label_context_backward(t, conv.weight.detach(), unary, grad_logq=G, conv_b=conv.bias.detach(),
+                                          la_w=mod.local_activation_function.weight.detach(), la_b=mod.local_activation_function.bias.detach(),
+                                          ga_w=mod.global_activation_function.weight.detach(), ga_b=mod.global_activation_function.bias.detach())
+bw()
+ms = timed(bw)
+print(f"label context backward (forward recomputed + data gradient + weight gradient): {ms:.3f} ms  "
+      f"{3 * flops / ms / 1e9:.1f} TFLOP/s over its three convolution-sized GEMMs")

@@ -15,6 +15,8 @@ def timed(f, n=5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); f(); e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1))
     return float(np.median(ts))
+dy = torch.randn(1, 21, 64, 64, device="cuda", generator=g)
 for name, f in (("local_forward", lambda: S.ops.local_forward(unary, pw, cw, 50, image=img)),
+                ("local_backward", lambda: S.ops.local_backward(unary, pw, cw, 50, dy, image=img)),
                 ("meanfield K=1", lambda: S.ops.meanfield_forward(unary, img, pw, cw, 50, 1))):
     f(); print("%-14s B1 C21 64x64 k50: %.3f ms" % (name, timed(f)))
