@@ -268,6 +268,34 @@ int mfl_label_context_backward(const float *t, const float *la_w, const float *l
 int mfl_iou_counts(const unsigned char *pred, const unsigned char *target, unsigned long long *counts, size_t n, int C,
                    mfl_stream_t stream);
 
+/*
+ * The image preprocessing in front of the path, on the device: what DPNModel._preprocess
+ * (AdvancedModel.py:487-498: transforms.Resize((H, W)), ToTensor, Normalize) does per image on the
+ * host.  Resize on a PIL image is Pillow's two-pass bilinear resampling of the 8-bit pixels with
+ * fixed-point coefficients and an 8-bit intermediate; the caller computes the coefficient tables
+ * on the host exactly as Pillow does (semantic_segmentation_amd/preprocess.py:
+ * resample_tables) and the kernels apply them in integer arithmetic, so the resized 8-bit image
+ * equals Pillow's bit for bit; out = ((pixel / 255) - mean) / std in fp32 as torchvision computes it.
+ *   src:     [H0][W0][3] uint8 RGB (device)         out: [3][H][W] fp32
+ *   xcoef:   [W][xksize] int32, xbounds: [W][2] = {first input column, count}; NULL when W == W0
+ *   ycoef:   [H][yksize] int32, ybounds: [H][2]; NULL when H == H0 (device pointers)
+ *   mean, stdev: 3 floats each, HOST pointers (read during the call)
+ *   workspace: mfl_preprocess_workspace_bytes() (the 8-bit image after the horizontal pass)
+ */
+size_t mfl_preprocess_workspace_bytes(int H0, int W0, int H, int W);
+int mfl_preprocess_rgb8(const unsigned char *src, int H0, int W0, const int *xcoef, const int *xbounds, int xksize,
+                        const int *ycoef, const int *ybounds, int yksize, const float *mean, const float *stdev,
+                        float *out, int H, int W, void *workspace, size_t workspace_bytes, mfl_stream_t stream);
+
+/*
+ * Nearest-neighbour resize of an annotated image (8-bit label map), what DPNModel.fit applies to
+ * the ground truth with PIL's default filter for palette images (AdvancedModel.py:265):
+ * out[y][x] = src[yin[y]][xin[x]], the source indices computed on the host as Pillow does
+ * (preprocess.py: nearest_indices).   src: [H0][W0], out: [H][W], yin: [H], xin: [W] int32 (device).
+ */
+int mfl_resize_labels(const unsigned char *src, int H0, int W0, const int *yin, const int *xin, unsigned char *out, int H,
+                      int W, mfl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,8 +2,9 @@
 
 Importing this package loads libmfl.so; it fails if the HIP extension has not been built.
 """
-from . import _lib, ops, parallel, training  # noqa: F401
+from . import _lib, ops, parallel, preprocess, training  # noqa: F401
 from .local_convolution import ColorDistanceHandle, Conv2dLocal, color_distance  # noqa: F401
 from .meanfield import LabelContext, LinearActivation, MeanFieldLocal  # noqa: F401
+from .dpn import DPNHead  # noqa: F401
 
-__all__ = ["Conv2dLocal", "ColorDistanceHandle", "color_distance", "MeanFieldLocal", "LabelContext", "LinearActivation", "ops", "parallel", "training"]
+__all__ = ["Conv2dLocal", "ColorDistanceHandle", "color_distance", "MeanFieldLocal", "LabelContext", "LinearActivation", "DPNHead", "ops", "parallel", "preprocess", "training"]

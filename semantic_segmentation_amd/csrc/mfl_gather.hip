@@ -30,8 +30,10 @@ __device__ __forceinline__ const int *stage_table(const int *__restrict__ tab_g,
     }
 }
 
+#if MFL_KIND != 3
 // tap-split kernels (large windows on small images): threads per pixel, pixels per workgroup
 constexpr int kTapSlices = 16, kTapPixels = kThreads / kTapSlices;
+#endif
 
 #if MFL_KIND == 1
 // y[b][c][l] = x[b][c][l] * sum_t w[b][l][t] * S[b][c][l][t]

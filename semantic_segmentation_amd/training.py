@@ -66,6 +66,41 @@ def fit(model: nn.Module, optimizer: torch.optim.Optimizer,
     return history
 
 
+def fit_incremental(model: nn.Module, optimizer: torch.optim.Optimizer,
+                    batches: Callable[[], Iterable[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]], epochs: int,
+                    weight: Optional[torch.Tensor] = None, incremental: bool = True, global_batch: Optional[int] = None,
+                    group=None, on_epoch: Optional[Callable[[int, int, float], None]] = None) -> list:
+    """The reference's incremental training (AdvancedModel.py:364-381) for a model with `forward_from_unary(unary,
+    image, phase)` and `set_phase_trainable(phase_index)` (DPNHead): `epochs` epochs per phase, phases 1 .. 4, the
+    layers frozen and released as the reference does, ONE optimiser for all phases; without `incremental` a single
+    run of the last phase.  `batches()` yields (unary or None, image, labels): with None the model's own unary
+    network produces the scores from the image.  Returns one list of epoch losses per phase."""
+    phases = range(model.NUM_PHASES) if incremental else [model.NUM_PHASES - 1]
+    histories = []
+    for phase_index in phases:
+        if incremental:
+            model.set_phase_trainable(phase_index)
+        phase = phase_index + 1
+        history = []
+        for epoch in range(epochs):
+            epoch_loss = 0.0
+            for unary, image, labels in batches():
+                optimizer.zero_grad(set_to_none=True)
+                share = 1.0 if global_batch is None else image.shape[0] / float(global_batch)
+                out = model(image, phase) if unary is None else model.forward_from_unary(unary, image, phase)
+                loss = per_image_nll(out, labels, weight) * share
+                if loss.requires_grad:                 # (a phase whose layers are all frozen has nothing to train)
+                    loss.backward()
+                    parallel.allreduce_gradients(model.parameters(), group)
+                    optimizer.step()
+                epoch_loss += float(loss.detach())
+            history.append(epoch_loss)
+            if on_epoch is not None:
+                on_epoch(phase, epoch, epoch_loss)
+        histories.append(history)
+    return histories
+
+
 def save_checkpoint(path: str, model: nn.Module, optimizer: torch.optim.Optimizer, epoch: Optional[int] = None,
                     phase: Optional[int] = None, loss: Optional[float] = None) -> None:
     """The reference's checkpoint dictionary: "model_state_dict" and "optimizer_state_dict", plus "epoch", "phase",

@@ -434,6 +434,33 @@ def gen_fit_step(LC, AM):
     save("fitstep_l6_h12_w80_k3", **out)
 
 
+def gen_preprocess():
+    """DPNModel._preprocess (AdvancedModel.py:487-498) = transforms.Resize((H, W)) -> ToTensor -> Normalize.
+    torchvision is not installed here; on a PIL image its Resize is `image.resize((W, H), Image.BILINEAR)`, ToTensor is
+    uint8 HWC -> float CHW / 255 and Normalize is (x - mean) / std in float32: those calls are made on real Pillow and
+    torch below ("restated from torchvision's documented behaviour": the fixture pins Pillow's resampling, which is
+    where all the arithmetic of the resize lives).  Labels: `image.resize(size)` on a palette image = nearest
+    (AdvancedModel.py:265)."""
+    from PIL import Image
+    rng = np.random.default_rng(1111)
+    out = {}
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+    for ci, (H0, W0, H, W) in enumerate([(37, 53, 64, 64), (120, 90, 64, 64), (64, 64, 64, 64), (75, 100, 32, 96), (50, 64, 100, 64)]):
+        # smooth + noise, so that both interpolation and antialiasing matter
+        yy, xx = np.mgrid[0:H0, 0:W0]
+        base = 127 + 100 * np.sin(xx / 7.0 + ci)[..., None] * np.cos(yy / 5.0)[..., None] * np.array([1.0, 0.7, -0.8])
+        a = np.clip(base + rng.normal(0, 25, (H0, W0, 3)), 0, 255).astype(np.uint8)
+        resized = np.array(Image.fromarray(a, "RGB").resize((W, H), Image.BILINEAR))
+        t = torch.from_numpy(resized).permute(2, 0, 1).contiguous().float().div(255)
+        t = t.sub(mean).div(std)
+        lab = rng.integers(0, 21, (H0, W0)).astype(np.uint8)
+        lab[rng.random((H0, W0)) < 0.05] = 255
+        lab_resized = np.array(Image.fromarray(lab, "P").resize((W, H)))
+        out.update({f"image{ci}": a, f"resized{ci}": resized, f"tensor{ci}": npy(t), f"labels{ci}": lab,
+                    f"labels_resized{ci}": lab_resized, f"size{ci}": np.array([H, W], np.int64)})
+    save("preprocess_rgb", **out)
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None, help="run one generator (e.g. meanfield_grad)")
@@ -443,7 +470,7 @@ def main():
     LC, AM = import_reference(args.reference)
     only = {"meanfield_grad": lambda: gen_meanfield_grad(LC, AM), "metrics": lambda: gen_metrics(AM),
             "tail_grad": lambda: gen_tail_grad(AM), "dpn_grad": lambda: gen_dpn_grad(AM),
-            "fit_step": lambda: gen_fit_step(LC, AM)}
+            "fit_step": lambda: gen_fit_step(LC, AM), "preprocess": gen_preprocess}
     if args.only is not None:
         only[args.only]()
         return
@@ -457,6 +484,7 @@ def main():
     gen_tail_grad(AM)
     gen_dpn_grad(AM)
     gen_fit_step(LC, AM)
+    gen_preprocess()
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ HEADER = os.path.join(ROOT, "include", "mfl.h")
 def declared_functions():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(mfl_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(mfl_[a-z0-9_]+)\s*\(", text)))
 
 
 @pytest.fixture(scope="module")

@@ -291,3 +291,96 @@ def test_large_window_backward_vs_oracle_and_bitwise_reproducible(shape, S, orac
         assert_close(host(dx), rdx, RTOL, "dx")
         assert abs(float(dpar[0]) - rdpw) <= 2e-4 * abs(rdpw) + 1e-5, (float(dpar[0]), rdpw)
         assert abs(float(dpar[1]) - rdcw) <= 2e-4 * abs(rdcw) + 1e-5, (float(dpar[1]), rdcw)
+
+
+# ------------------------------------------------------------------ DPN head, phase schedule, preprocessing
+def _dpn_head_from(d, S):
+    B, L, H, W = d["unary"].shape
+    head = S.DPNHead(H, W, num_labels=L, num_mixture_filters=int(d["mixtures"]), kernel_size=(int(d["k"]), int(d["k"]))).cuda()
+    with torch.no_grad():
+        head.local_convolution_layer.position_weight.fill_(float(d["pw"]))
+        head.local_convolution_layer.color_weight.fill_(float(d["cw"]))
+        head.local_activation_function.weight.copy_(dev(d["la_w"]))
+        head.local_activation_function.bias.copy_(dev(d["la_b"]))
+        head.global_convolution_layer.weight.copy_(dev(d["conv_w"]))
+        head.global_convolution_layer.bias.copy_(dev(d["conv_b"]))
+        head.global_activation_function.weight.copy_(dev(d["ga_w"]))
+        head.global_activation_function.bias.copy_(dev(d["ga_b"]))
+    return head
+
+
+def test_dpn_head_phases_match_the_reference_model(S):
+    """DPNHead.forward_from_unary(phase = 2, 3, 4) against DPNModel.forward with the unary network bypassed
+    (AdvancedModel.py:198-244), outputs and, for phases 3 and 4, every gradient."""
+    d = load(golden_files("dpn")[0])
+    head = _dpn_head_from(d, S)
+    with torch.no_grad():
+        for phase in (2, 3, 4):
+            out = head.forward_from_unary(dev(d["unary"]), dev(d["img"]), phase)
+            assert_close(host(out), d[f"phase{phase}"], RTOL, f"phase {phase}")
+        assert_close(host(head.forward_from_unary(dev(d["unary"]), dev(d["img"]), 1)),
+                     host(torch.log_softmax(dev(d["unary"]), dim=1)), 1e-6, "phase 1")
+    d = load(golden_files("dpngrad")[0])
+    head = _dpn_head_from(d, S)
+    names = {"dpw": head.local_convolution_layer.position_weight, "dcw": head.local_convolution_layer.color_weight,
+             "dla_w": head.local_activation_function.weight, "dla_b": head.local_activation_function.bias,
+             "dconv_w": head.global_convolution_layer.weight, "dconv_b": head.global_convolution_layer.bias,
+             "dga_w": head.global_activation_function.weight, "dga_b": head.global_activation_function.bias}
+    for phase in (3, 4):
+        head.zero_grad(set_to_none=True)
+        U = dev(d["unary"]).requires_grad_(True)
+        out = head.forward_from_unary(U, dev(d["img"]), phase)
+        assert_close(host(out), d[f"out_p{phase}"], RTOL, f"phase {phase} output")
+        (out * dev(d["G"])).sum().backward()
+        assert_close(host(U.grad), d[f"dunary_p{phase}"], RTOL, f"phase {phase} d unary")
+        for key, p in names.items():
+            want = d[f"{key}_p{phase}"]
+            if key in ("dpw", "dcw"):
+                assert abs(float(p.grad) - float(want[0])) <= 2e-4 * abs(float(want[0])), (phase, key)
+            else:
+                assert_close(host(p.grad), want, RTOL, f"phase {phase} {key}")
+
+
+def test_incremental_training_follows_the_phase_schedule(S):
+    """training.fit_incremental on a DPNHead (AdvancedModel.py:364-381): four phases with one optimiser; a phase
+    moves exactly the layers the reference leaves trainable in it and the loss of every trained phase goes down."""
+    from semantic_segmentation_amd import training
+    B, L, H, W, k = 2, 5, 24, 80, 5
+    unary, img, _ = make_inputs((B, L, H, W, k), 97)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    labels = torch.randint(0, L, (B, H, W), device="cuda", generator=g)
+    labels[torch.rand(B, H, W, device="cuda", generator=g) < 0.05] = 255
+    head = S.DPNHead(H, W, num_labels=L, num_mixture_filters=2, kernel_size=(k, k), context_kernel_size=3).cuda()
+    opt = torch.optim.Adam(head.parameters(), lr=2e-4)          # (the reference trains with Adam, AdvancedModel.py:8, 352)
+    snap = lambda: {n: p.detach().clone() for n, p in head.named_parameters()}
+    states = [snap()]
+    losses = training.fit_incremental(head, opt, lambda: [(dev(unary), dev(img), labels)], epochs=4,
+                                      on_epoch=lambda phase, epoch, loss: states.append(snap()) if epoch == 3 else None)
+    assert len(losses) == 4 and all(len(h) == 4 and np.isfinite(h).all() for h in losses)
+    moved = lambda a, b, prefix: any((a[n] != b[n]).any() for n in a if n.startswith(prefix))
+    # phase 1: only the (absent) unary network has a gradient: nothing of the head moves
+    assert not moved(states[0], states[1], "")
+    # phase 2: the local layers train, the context block does not see a gradient yet
+    assert moved(states[1], states[2], "local_convolution_layer") and moved(states[1], states[2], "local_activation_function")
+    assert not moved(states[1], states[2], "global_")
+    # phase 3: the local layers are frozen, the context block trains
+    assert not moved(states[2], states[3], "local_") and moved(states[2], states[3], "global_convolution_layer")
+    # phase 4: everything trains
+    assert moved(states[3], states[4], "local_convolution_layer") and moved(states[3], states[4], "global_activation_function")
+    for phase in (1, 2, 3):
+        assert losses[phase][-1] < losses[phase][0], (phase + 1, losses[phase])
+
+
+def test_device_preprocessing_equals_pillow_and_torchvision_arithmetic(S):
+    """preprocess.preprocess / resize_labels (resize, /255, normalise on the device from the raw 8-bit pixels) against
+    Pillow's resize followed by ToTensor and Normalize (AdvancedModel.py:265, 487-498): bit for bit."""
+    d = load(golden_files("preprocess")[0])
+    for ci in range(5):
+        H, W = (int(v) for v in d[f"size{ci}"])
+        got = host(S.preprocess.preprocess([d[f"image{ci}"]], H, W))
+        assert np.array_equal(got[0], d[f"tensor{ci}"]), f"image {ci}: max diff {np.abs(got[0] - d[f'tensor{ci}']).max()}"
+        lab = host(S.preprocess.resize_labels([d[f"labels{ci}"]], H, W))
+        assert np.array_equal(lab[0], d[f"labels_resized{ci}"]), ci
+    # a batch of images of different sizes in one call
+    both = host(S.preprocess.preprocess([d["image0"], d["image1"]], 64, 64))
+    assert np.array_equal(both[0], d["tensor0"]) and np.array_equal(both[1], d["tensor1"])

@@ -111,3 +111,59 @@ def test_checkpoint_format_round_trip(tmp_path):
     torch.save({"model_state_dict": sd, "optimizer_state_dict": {"state": {}, "param_groups": []}}, path)
     info = training.load_checkpoint(path, m2, torch.optim.SGD(m2.parameters(), lr=0.1))
     assert info["unexpected"] == ["unary_terms_layers.0.weight"] and not info["optimizer_loaded"]
+
+
+def test_resample_tables_reproduce_pillow_fixture():
+    """Host logic of the device preprocessing: the windows and fixed-point coefficients of preprocess.resample_tables,
+    applied in integer arithmetic with numpy, give Pillow's resized 8-bit image bit for bit (fixture made by Pillow,
+    tests/golden/make_golden.py: gen_preprocess); nearest_indices gives Pillow's nearest-neighbour label resize."""
+    import numpy as np
+    from conftest import golden_files, load
+    from semantic_segmentation_amd import preprocess as P
+    d = load(golden_files("preprocess")[0])
+
+    def axis_pass(img, axis, out_size):
+        coef, bounds = P.resample_tables(img.shape[axis], out_size)
+        img = np.moveaxis(img, axis, 0).astype(np.int64)
+        out = np.empty((out_size,) + img.shape[1:], np.uint8)
+        for i in range(out_size):
+            lo, n = bounds[i]
+            acc = (1 << (P.PRECISION_BITS - 1)) + np.tensordot(coef[i, :n].astype(np.int64), img[lo:lo + n], axes=1)
+            out[i] = np.clip(acc >> P.PRECISION_BITS, 0, 255)
+        return np.moveaxis(out, 0, axis)
+
+    for ci in range(5):
+        a, (H, W) = d[f"image{ci}"], d[f"size{ci}"]
+        r = a if a.shape[1] == W else axis_pass(a, 1, int(W))
+        r = r if r.shape[0] == H else axis_pass(r, 0, int(H))
+        assert np.array_equal(r, d[f"resized{ci}"]), ci
+        lab = d[f"labels{ci}"]
+        got = lab[P.nearest_indices(lab.shape[0], int(H))][:, P.nearest_indices(lab.shape[1], int(W))]
+        assert np.array_equal(got, d[f"labels_resized{ci}"]), ci
+
+
+def test_dpn_head_keeps_the_reference_state_dict_keys_and_phase_schedule():
+    import torch
+    import semantic_segmentation_amd as S
+    unary_net = torch.nn.Conv2d(3, 4, 1)
+    head = S.DPNHead(8, 9, num_labels=4, num_mixture_filters=5, unary_terms_layers=unary_net)
+    keys = set(head.state_dict())
+    for k in ("local_convolution_layer.color_weight", "local_convolution_layer.position_weight",
+              "local_convolution_layer.position_distances", "local_activation_function.weight",
+              "global_convolution_layer.weight", "global_convolution_layer.bias", "global_activation_function.bias",
+              "unary_terms_layers.weight"):
+        assert k in keys
+    assert head.global_convolution_layer.weight.shape == (20, 4, 9, 9)
+    trainable = lambda m: all(p.requires_grad for p in m.parameters())
+    # AdvancedModel.py:364-377
+    head.set_phase_trainable(0)
+    assert trainable(unary_net) and trainable(head.local_convolution_layer)
+    head.set_phase_trainable(1)
+    assert not trainable(unary_net) and trainable(head.local_convolution_layer)
+    head.set_phase_trainable(2)
+    assert not trainable(head.local_convolution_layer) and not trainable(head.local_activation_function)
+    assert trainable(head.global_convolution_layer)
+    head.set_phase_trainable(3)
+    assert trainable(unary_net) and trainable(head.local_convolution_layer) and trainable(head.local_activation_function)
+    with pytest.raises(ValueError):
+        head.forward_from_unary(torch.zeros(1, 4, 8, 9), torch.zeros(1, 3, 8, 9), phase=5)
