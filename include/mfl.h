@@ -103,10 +103,13 @@ int mfl_local_forward(const float *x, const float *img, const float *cd, const f
  *   dcd:     optional [B][H*W][k*k] gradient w.r.t. the colour-distance tensor
  *            (NULL to skip; only allowed with `cd`)
  * With `img` on shapes the diagonal kernels serve (images at least 64 pixels
- * wide, window 3..11) the scatter half of dx is summed in 64-bit fixed point
- * (integer atomics): dx is reproducible bit for bit.  The other paths (a `cd`
- * tensor, small or very wide windows) use float atomics, whose summation order
- * and therefore last bits can differ between runs.
+ * wide, window 3..11; more than 33 labels block by block of output channels) and
+ * on large windows over small images (at least 16 x 16 taps on at most 64 K
+ * pixels: the reference model's own 50 x 50 window on 64 x 64) the scatter half
+ * of dx is summed in 64-bit fixed point (integer atomics): dx is reproducible bit
+ * for bit.  The other paths (a `cd` tensor, narrow images, even windows on large
+ * images) use float atomics, whose summation order and therefore last bits can
+ * differ between runs.
  */
 int mfl_local_backward(const float *x, const float *img, const float *cd, const float *pos_w, const float *col_w,
                        const float *dy, float *dx, float *dparams, float *dcd, int B, int C, int H, int W, int k,
@@ -165,8 +168,9 @@ int mfl_meanfield_forward_iterates(const float *unary, const float *img, const f
  *   dparams:    2 floats, overwritten with {d position_weight, d color_weight}
  *   d_affine_w, d_affine_b: [C][H][W], overwritten; non-NULL exactly when affine_w is
  *   d_compat:   [C][C], overwritten; non-NULL exactly when compat is
- * C <= 32.  All sums over images and pixels outside the local operator's own
- * backward have a fixed order.  The address tables of the nested operator calls
+ * C <= 160 (up to 32 labels a pixel's channel vectors stay in one lane's registers;
+ * above that the label products run as GEMMs on the fp32 matrix instructions).  All sums
+ * over images and pixels outside the local operator's own backward have a fixed order.  The address tables of the nested operator calls
  * are rebuilt once per call (their plan tag lies inside this workspace and is
  * cleared on entry), so the workspace may be any memory, whatever it held before.
  */

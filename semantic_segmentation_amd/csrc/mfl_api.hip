@@ -671,6 +671,28 @@ BlockWorkspace block_carve(int op, const DiagGeom &g)
     return w;
 }
 
+// The local backward block by block of output channels (more than 33 labels): the forward's padded planes, image and
+// per-block tables, plus what the diagonal backward adds (fixed-point gradient planes, plain window sums, constants).
+struct BlockBackwardWorkspace {
+    BlockWorkspace f;
+    size_t dxp, psum, qsum, consts, partials, total;
+};
+
+BlockBackwardWorkspace block_backward_carve(const DiagGeom &g)
+{
+    BlockBackwardWorkspace w{};
+    w.f = block_carve(MFL_OP_LOCAL_FORWARD, g);
+    size_t off = w.f.total;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    w.dxp = take(diag_padded_floats(g) * 8);
+    w.psum = take((size_t)g.B * g.C * g.L * 4);
+    w.qsum = take((size_t)g.B * g.C * g.L * 4);
+    w.consts = take(8 * 4);
+    w.partials = take((size_t)2 * kDiagBackwardBlocks * 4);
+    w.total = off;
+    return w;
+}
+
 // The geometry of block `blk` of a block geometry.
 DiagGeom block_geom(const DiagGeom &g, int blk)
 {
@@ -753,7 +775,7 @@ int block_prepare(int op, void *workspace, const DiagGeom &bg, const BlockWorksp
 
 // y = x * window sums of the padded planes xp, one launch per channel block.
 int block_window_products(void *workspace, const DiagGeom &bg, const BlockWorkspace &ws, const float *xp, const float *pos_w,
-                          const float *col_w, float *y, hipStream_t st)
+                          const float *col_w, float *y, hipStream_t st, int mode = 1)
 {
     char *base = (char *)workspace;
     DiagArgs da{};
@@ -767,7 +789,7 @@ int block_window_products(void *workspace, const DiagGeom &bg, const BlockWorksp
     for (int blk = 0; blk < ws.nblk; ++blk) {
         da.g = block_geom(bg, blk);
         da.table = (const uint32_t *)(base + ws.table + blk * ws.table_stride);
-        const int rc = dispatch_diag(da, 1, st);
+        const int rc = dispatch_diag(da, mode, st);
         if (rc) return rc;
     }
     return MFL_OK;
@@ -961,10 +983,10 @@ size_t mfl_workspace_bytes(int op, int B, int C, int H, int W, int k, int iters)
     Geom g;
     if (make_geom(g, B, C, H, W, k, 1)) return 0;
     size_t generic = carve(op, g, pick_cc(C)).total;
-    if (op != MFL_OP_LOCAL_BACKWARD && diag_block_eligible(B, C, H, W, k, dg)) {
+    if (diag_block_eligible(B, C, H, W, k, dg)) {
         // (more than 33 labels: the diagonal kernels block by block with an image, and in the loop with a label
         // matrix; the generic ones otherwise)
-        const size_t blocks = block_carve(op, dg).total;
+        const size_t blocks = op == MFL_OP_LOCAL_BACKWARD ? block_backward_carve(dg).total : block_carve(op, dg).total;
         if (blocks > generic) generic = blocks;
     }
     // the backward takes the diagonal kernels with an image and the generic ones with a cd tensor
@@ -1386,14 +1408,34 @@ namespace mfl {
 bool local_backward_split_supported(int B, int C, int H, int W, int k)
 {
     DiagGeom dg;
-    return diag_eligible(MFL_OP_LOCAL_BACKWARD, B, C, H, W, k, dg);
+    return diag_eligible(MFL_OP_LOCAL_BACKWARD, B, C, H, W, k, dg) || diag_block_eligible(B, C, H, W, k, dg);
 }
 
 int local_backward_sums(const float *x, const float *img, int B, int C, int H, int W, int k, void *workspace, size_t workspace_bytes,
                         mfl_stream_t stream, const float **Pout, const float **Qout)
 {
     DiagGeom dg;
-    if (!x || !img || !diag_eligible(MFL_OP_LOCAL_BACKWARD, B, C, H, W, k, dg)) return MFL_ERR_INVALID_ARGUMENT;
+    if (!x || !img) return MFL_ERR_INVALID_ARGUMENT;
+    if (diag_block_eligible(B, C, H, W, k, dg)) {
+        // more than 33 labels: block by block of output channels
+        const BlockBackwardWorkspace ws = block_backward_carve(dg);
+        if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
+        char *base = (char *)workspace;
+        hipStream_t st = (hipStream_t)stream;
+        float *xp = (float *)(base + ws.f.xp);
+        int rc = block_prepare(MFL_OP_LOCAL_BACKWARD, workspace, dg, ws.f, x, img, xp, st);
+        if (rc) return rc;
+        float *consts = (float *)(base + ws.consts), *P = (float *)(base + ws.psum), *Q = (float *)(base + ws.qsum);
+        hipLaunchKernelGGL(diag_backward_consts_kernel, dim3(1), dim3(64), 0, st, consts);
+        rc = block_window_products(workspace, dg, ws.f, xp, consts, consts + 1, P, st, 2);
+        if (rc) return rc;
+        rc = block_window_products(workspace, dg, ws.f, xp, consts + 2, consts + 3, Q, st, 2);
+        if (rc) return rc;
+        *Pout = P;
+        *Qout = Q;
+        return MFL_OK;
+    }
+    if (!diag_eligible(MFL_OP_LOCAL_BACKWARD, B, C, H, W, k, dg)) return MFL_ERR_INVALID_ARGUMENT;
     const DiagWorkspace ws = diag_carve(MFL_OP_LOCAL_BACKWARD, dg);
     if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
     char *base = (char *)workspace;
@@ -1426,8 +1468,41 @@ int local_backward_apply(const float *x, const float *img, const float *pos_w, c
                          mfl_stream_t stream)
 {
     DiagGeom dg;
-    if (!x || !img || !dy || !dx || !dparams || !diag_eligible(MFL_OP_LOCAL_BACKWARD, B, C, H, W, k, dg))
-        return MFL_ERR_INVALID_ARGUMENT;
+    if (!x || !img || !dy || !dx || !dparams) return MFL_ERR_INVALID_ARGUMENT;
+    if (diag_block_eligible(B, C, H, W, k, dg)) {
+        const BlockBackwardWorkspace ws = block_backward_carve(dg);
+        if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
+        char *base = (char *)workspace;
+        hipStream_t st = (hipStream_t)stream;
+        float *consts = (float *)(base + ws.consts), *P = (float *)(base + ws.psum), *Q = (float *)(base + ws.qsum);
+        float *dxp = (float *)(base + ws.dxp), *partials = (float *)(base + ws.partials);   // (dxp: 64-bit elements)
+        const size_t n = (size_t)B * C * dg.L;
+        hipLaunchKernelGGL(diag_backward_absmax_kernel, dim3(grid_for(n) < 1024 ? grid_for(n) : 1024), dim3(kThreads), 0, st, dy, x, n, img,
+                           (size_t)B * 3 * dg.L, consts);
+        hipLaunchKernelGGL(diag_backward_scale_kernel, dim3(1), dim3(64), 0, st, pos_w, col_w, k, consts);
+        MFL_CHECK_HIP(hipMemsetAsync(dxp, 0, diag_padded_floats(dg) * 8, st));
+        DiagArgs da{};
+        diag_lds(dg, da);
+        da.xp = (const float *)(base + ws.f.xp);
+        da.ip4 = (const F4 *)(base + ws.f.ip4);
+        da.groups = (const uint32_t *)(base + ws.f.groups);
+        da.pos_w = pos_w; da.col_w = col_w; da.y = nullptr;
+        da.unary = dy;
+        da.qp_out = dxp;
+        da.aw = consts + 4;                       // the scatter's fixed-point scale
+        for (int blk = 0; blk < ws.f.nblk; ++blk) {
+            da.g = block_geom(dg, blk);
+            da.table = (const uint32_t *)(base + ws.f.table + blk * ws.f.table_stride);
+            const int rc = dispatch_diag(da, 3, st);
+            if (rc) return rc;
+        }
+        const int blocks = grid_for(n) < kDiagBackwardBlocks ? grid_for(n) : kDiagBackwardBlocks;
+        hipLaunchKernelGGL(diag_backward_finish_kernel, dim3(blocks), dim3(kThreads), 0, st, dy, x, P, Q, (const long long *)dxp + dg.FS, consts,
+                           pos_w, col_w, dx, partials, B * C, H, W, dg.Hp, dg.Wp, dg.p0);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kThreads), 0, st, partials, blocks, dparams);
+        return (int)hipGetLastError();
+    }
+    if (!diag_eligible(MFL_OP_LOCAL_BACKWARD, B, C, H, W, k, dg)) return MFL_ERR_INVALID_ARGUMENT;
     const DiagWorkspace ws = diag_carve(MFL_OP_LOCAL_BACKWARD, dg);
     if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
     char *base = (char *)workspace;

@@ -239,7 +239,7 @@ struct Loop {
     using Cfg = DiagCfg<CH, KS, NGW, NCS>;
     unsigned long long *scatter_out;        // BWD: FS elements before the image's zeroed padded planes of 64-bit fixed-point sums
     float fscale;                           // BWD: the fixed-point scale (a power of two)
-    int C, ci;                              // BWD: channels, this wave's channel split
+    int C, ci;                              // BWD: channels of the launch (a block of a larger label set, or all), this wave's channel split
     DiagState<CH, KS, NGW, NCS> &st;
     __amdgpu_buffer_rsrc_t rsrc;
     const uint32_t *__restrict__ table;    // records of this wave's (b-block, group, channel split), tap 0
@@ -664,16 +664,16 @@ diag_kernel(DiagGeom g, int epi_rows, int tail_per_group, const float *__restric
                 const bool ok = place(cb0, r, moff, l, cpos);
                 const int br = r / Cfg::RUN, a_rel = r - br * Cfg::RUN;
                 float *dst = lds + br * Cfg::RUNP + a_rel;
-                // all loads first (channels past C re-read channel C-1), then the stores
+                // all loads first (channels past the launch's block re-read its last one), then the stores
                 float dv[Cfg::CE], xv[Cfg::CE];
 #pragma unroll
                 for (int c = 0; c < Cfg::CE; ++c) {
-                    const int cc = c < C ? c : C - 1;
+                    const int cc = g.c0 + (c < g.Cv ? c : g.Cv - 1);
                     dv[c] = buf_load(rdy, l * 4, (uint32_t)(cc * L * 4));
                     xv[c] = buf_load(rxc, cpos * 4, (uint32_t)(cc * g.plane * 4));
                 }
 #pragma unroll
-                for (int c = 0; c < Cfg::CE; ++c) dst[c * cstride] = (ok && c < C) ? dv[c] * xv[c] : 0.f;
+                for (int c = 0; c < Cfg::CE; ++c) dst[c * cstride] = (ok && c < g.Cv) ? dv[c] * xv[c] : 0.f;
             }
             __syncthreads();
 #pragma unroll
@@ -688,7 +688,7 @@ diag_kernel(DiagGeom g, int epi_rows, int tail_per_group, const float *__restric
             __syncthreads();
         }
     }
-    Loop<CH, KS, NGW, NCS, MODE == 3> loop{reinterpret_cast<unsigned long long *>(qp_out) + img_off, MODE == 3 ? aw[0] : 0.f, C, ci, st, rsrc,
+    Loop<CH, KS, NGW, NCS, MODE == 3> loop{reinterpret_cast<unsigned long long *>(qp_out) + img_off, MODE == 3 ? aw[0] : 0.f, g.Cv, ci, st, rsrc,
                                            table + diag_record_index(g, beta, live ? gamma : 0, 0, ci), groups, irsrc, lds,
                                            pw, cw, g.ngroups, g.TB, g.NCS * g.RECW, g.RECW, g.p0, Wp, W, g.gap * 4, gi,
                                            lane, live, dbg};

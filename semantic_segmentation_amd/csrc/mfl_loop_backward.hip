@@ -232,9 +232,213 @@ __global__ void loop_final_kernel(const float *__restrict__ unary, const float *
     }
 }
 
+
+// ------------------------------------------------------------------ more than 32 labels
+// A pixel's channel vectors no longer fit one lane's registers, so the step is split: an elementwise kernel
+// (softmax backward, M_t, A_t), the label product dA = compat^T . dP and the matrix gradient dcompat += dP (x) A
+// as GEMMs on v_mfma_f32_32x32x2_f32 (fp32 in and out), and an elementwise kernel for the affine.  All sums over
+// images and pixels have a fixed order.
+
+// One thread per (image, pixel):  g = incoming gradient of logQ_{t+1} (from_dq: dQ_{t+1} * Q_{t+1});
+//   dz = g - Q * sum_c g;  dls (+)= dz;  dp = -dz;  M_t = m_in, or xq * (pos_w * P + col_w * Q) from the plain window
+//   sums;  a_out = aw * M + ab (or M).  m_out / a_out may be NULL.
+__global__ void __launch_bounds__(256)
+loop_softmax_grad_kernel(const float *__restrict__ g_in, int from_dq, const float *__restrict__ logq1, const float *__restrict__ m_in,
+                         const float *__restrict__ xq, const float *__restrict__ psum, const float *__restrict__ qsum,
+                         const float *__restrict__ pos_w, const float *__restrict__ col_w, const float *__restrict__ aw,
+                         const float *__restrict__ ab, float *__restrict__ dp, float *__restrict__ a_out, float *__restrict__ m_out,
+                         float *__restrict__ dls, int first, int B, int C, int L)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * L) return;
+    const size_t b = i / L, l = i - b * L;
+    const size_t base = b * C * L + l;
+    const float pw = m_in ? 0.f : *pos_w, cw = m_in ? 0.f : *col_w;
+    float sg = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const size_t o = base + (size_t)c * L;
+        sg += from_dq ? g_in[o] * __expf(logq1[o]) : g_in[o];
+    }
+    for (int c = 0; c < C; ++c) {
+        const size_t o = base + (size_t)c * L;
+        const float q = __expf(logq1[o]);
+        const float gv = from_dq ? g_in[o] * q : g_in[o];
+        const float dz = gv - q * sg;
+        dls[o] = first ? dz : dls[o] + dz;
+        dp[o] = -dz;
+        if (m_out || a_out) {
+            const float mv = m_in ? m_in[o] : xq[o] * fmaf(pw, psum[o], cw * qsum[o]);
+            if (m_out) m_out[o] = mv;
+            if (a_out) a_out[o] = aw ? fmaf(aw[(size_t)c * L + l], mv, ab[(size_t)c * L + l]) : mv;
+        }
+    }
+}
+
+constexpr int kMatWaves = 8;
+
+// out[b][j][l] = sum_i mat[i][j] * in[b][i][l]  (dA = compat^T . dP): the label step's GEMM (mfl_label_step.hip) without its
+// epilogue.  A wave owns tiles of 32 consecutive pixels; lane (p, h) supplies in[pixel p][channel 2s + h] per k-step
+// and the matrix rows come from a zero-padded copy in LDS; register v of block mb = out channel 32 mb + 8 (v/4) + 4 h + v%4.
+template <int MB>
+__global__ void __launch_bounds__(64 * kMatWaves)
+loop_matmul_kernel(const float *__restrict__ in, const float *__restrict__ mat, float *__restrict__ out, int B, int C, int L)
+{
+    extern __shared__ __attribute__((aligned(16))) float ct[];      // [2 * KJ][CP]: ct[i][j] = mat[i][j]
+    constexpr int CP = 32 * MB;
+    const int KJ = (C + 1) / 2;
+    for (int idx = threadIdx.x; idx < 2 * KJ * CP; idx += blockDim.x) {
+        const int i = idx / CP, j = idx - i * CP;
+        ct[idx] = (i < C && j < C) ? mat[(size_t)i * C + j] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    const long long npix = (long long)B * L;
+    const long long ntiles = (npix + 31) / 32;
+    for (long long tile = (long long)blockIdx.x * kMatWaves + wave; tile < ntiles; tile += (long long)gridDim.x * kMatWaves) {
+        const long long pix = tile * 32 + p;
+        const bool ok = pix < npix;
+        const long long pc = ok ? pix : npix - 1;
+        const int b = (int)(pc / L), l = (int)(pc - (long long)b * L);
+        const float *src = in + ((size_t)b * C) * L + l;
+        f16v d[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) d[mb][v] = 0.f;
+        constexpr int kAhead = 8;
+        for (int j0 = 0; j0 < KJ; j0 += kAhead) {
+            float av[kAhead];
+#pragma unroll
+            for (int jj = 0; jj < kAhead; ++jj) {
+                const int c2 = 2 * (j0 + jj) + h;
+                av[jj] = c2 < C ? src[(size_t)c2 * L] : 0.f;
+            }
+#pragma unroll
+            for (int jj = 0; jj < kAhead; ++jj) {
+                if (j0 + jj < KJ) {
+                    const float *row = ct + (2 * (j0 + jj) + h) * CP + p;
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) d[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(row[32 * mb], av[jj], d[mb], 0, 0, 0);
+                }
+            }
+        }
+        if (ok) {
+            float *dst = out + ((size_t)b * C) * L + l;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int c = 32 * mb + 8 * (v / 4) + 4 * h + (v % 4);
+                    if (c < C) dst[(size_t)c * L] = d[mb][v];
+                }
+        }
+    }
+}
+
+// dm = aw * dA;  daw (+)= sum_b dA * M;  dab (+)= sum_b dA.  One thread per (channel, pixel), looping over the batch.
+__global__ void __launch_bounds__(256)
+loop_affine_grad_kernel(const float *__restrict__ da, const float *__restrict__ m, const float *__restrict__ aw, float *__restrict__ dm,
+                        float *__restrict__ daw, float *__restrict__ dab, int first, int B, size_t CL)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= CL) return;
+    const float w = aw[i];
+    float sw = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float g = da[(size_t)b * CL + i];
+        dm[(size_t)b * CL + i] = w * g;
+        sw = fmaf(g, m[(size_t)b * CL + i], sw);
+        sb += g;
+    }
+    daw[i] = first ? sw : daw[i] + sw;
+    dab[i] = first ? sb : dab[i] + sb;
+}
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// Four consecutive floats of a plane row starting at pixel l; zeros past the plane's end (and for rows that do not exist).
+__device__ __forceinline__ f4u load4_guarded(const float *row, int l, int L, bool row_ok)
+{
+    f4u v = {0.f, 0.f, 0.f, 0.f};
+    if (!row_ok) return v;
+    if (l + 3 < L) return *reinterpret_cast<const f4u *>(row + l);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (l + q < L) v[q] = row[l + q];
+    return v;
+}
+
+// part[slice][cb][rb][i][j] = sum over the slice's pixels of dP[32 rb + i][pixel] * A[32 cb + j][pixel]: a GEMM with the
+// pixels as the contraction.  One wave per (column block cb, slice); a slice is a run of tiles of 64 consecutive pixels of
+// one image; per matrix instruction lane (p, h) supplies row / column p at pixel 32 h + s of the tile, so every lane walks
+// 32 consecutive floats of its own channel plane, four at a time.
+template <int MB>
+__global__ void __launch_bounds__(256)
+loop_dcompat_kernel(const float *__restrict__ dp, const float *__restrict__ a, float *__restrict__ part, int B, int C, int L, int nsl,
+                    int tiles_per_slice, int tiles_per_image)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    const long long unit = (long long)blockIdx.x * 4 + wave;
+    if (unit >= (long long)MB * nsl) return;
+    const int cb = (int)(unit % MB), sl = (int)(unit / MB);
+    const long long ntiles = (long long)B * tiles_per_image;
+    const long long t0 = (long long)sl * tiles_per_slice;
+    const long long t1 = t0 + tiles_per_slice < ntiles ? t0 + tiles_per_slice : ntiles;
+    const bool col_ok = 32 * cb + p < C;
+    f16v d[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) d[mb][v] = 0.f;
+    for (long long tile = t0; tile < t1; ++tile) {
+        const int b = (int)(tile / tiles_per_image);
+        const int l0 = (int)(tile - (long long)b * tiles_per_image) * 64 + 32 * h;
+        const float *acol = a + ((size_t)b * C + (col_ok ? 32 * cb + p : 0)) * L;
+#pragma unroll 2
+        for (int s = 0; s < 32; s += 4) {
+            const f4u bv = load4_guarded(acol, l0 + s, L, col_ok);
+            f4u av[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const bool row_ok = 32 * mb + p < C;
+                av[mb] = load4_guarded(dp + ((size_t)b * C + (row_ok ? 32 * mb + p : 0)) * L, l0 + s, L, row_ok);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) d[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb][q], bv[q], d[mb], 0, 0, 0);
+        }
+    }
+    float *out = part + ((size_t)sl * MB + cb) * (size_t)(MB * 1024);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) out[mb * 1024 + (8 * (v / 4) + 4 * h + (v % 4)) * 32 + p] = d[mb][v];
+}
+
+// dcompat[i][j] (+)= sum over the slices, in order, of part[slice][j / 32][i / 32][i % 32][j % 32]
+__global__ void __launch_bounds__(256)
+loop_dcompat_reduce_kernel(const float *__restrict__ part, float *__restrict__ dcompat, int C, int MB, int nsl, int first)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= C * C) return;
+    const int i = idx / C, j = idx - i * C;
+    const size_t at = ((size_t)(j >> 5) * MB + (i >> 5)) * 1024 + (size_t)(i & 31) * 32 + (j & 31);
+    float sum = 0.f;
+    for (int sl = 0; sl < nsl; ++sl) sum += part[(size_t)sl * MB * MB * 1024 + at];
+    dcompat[idx] = first ? sum : dcompat[idx] + sum;
+}
+
+constexpr int kMaxLargeC = 160;
+constexpr int kDcompatWaves = 4096;
+
 struct LoopWorkspace {
     size_t logq_all, x, m, dm, dx, dls, dpar, part, ct32, sub, sub_bytes, total;
+    size_t dp, abuf, da;             // more than 32 labels only
     int nblk;
+    int mb, nsl, tiles_per_slice, tiles_per_image;
 };
 
 LoopWorkspace loop_carve(int B, int C, int H, int W, int k, int iters)
@@ -252,8 +456,23 @@ LoopWorkspace loop_carve(int B, int C, int H, int W, int k, int iters)
     w.dls = take(n);
     w.dpar = take((size_t)iters * 2 * 4);
     w.nblk = (L + kPix - 1) / kPix;
-    w.part = take((size_t)w.nblk * C * C * 4);
-    w.ct32 = take(32 * 32 * 4);
+    if (C <= kMaxC) {
+        w.part = take((size_t)w.nblk * C * C * 4);
+        w.ct32 = take(32 * 32 * 4);
+    } else {
+        w.dp = take(n);
+        w.abuf = take(n);
+        w.da = take(n);
+        w.mb = (C + 31) / 32;
+        w.tiles_per_image = (L + 63) / 64;
+        const long long ntiles = (long long)B * w.tiles_per_image;
+        long long nsl = kDcompatWaves / w.mb;
+        if (nsl < 1) nsl = 1;
+        if (nsl > ntiles) nsl = ntiles;
+        w.tiles_per_slice = (int)((ntiles + nsl - 1) / nsl);
+        w.nsl = (int)((ntiles + w.tiles_per_slice - 1) / w.tiles_per_slice);
+        w.part = take((size_t)w.nsl * w.mb * w.mb * 1024 * 4);
+    }
     size_t sub = mfl_workspace_bytes(MFL_OP_MEANFIELD_FORWARD, B, C, H, W, k, iters);
     const size_t f = mfl_workspace_bytes(MFL_OP_LOCAL_FORWARD, B, C, H, W, k, 1);
     const size_t bw = mfl_workspace_bytes(MFL_OP_LOCAL_BACKWARD, B, C, H, W, k, 1);
@@ -284,7 +503,7 @@ int meanfield_forward_keep(const float *unary, const float *img, const float *po
 
 size_t loop_backward_workspace_bytes(int B, int C, int H, int W, int k, int iters)
 {
-    if (B <= 0 || C <= 0 || C > kMaxC || H <= 0 || W <= 0 || k <= 0 || iters <= 0) return 0;
+    if (B <= 0 || C <= 0 || C > kMaxLargeC || H <= 0 || W <= 0 || k <= 0 || iters <= 0) return 0;
     if (mfl_workspace_bytes(MFL_OP_LOCAL_BACKWARD, B, C, H, W, k, 1) == 0) return 0;
     return loop_carve(B, C, H, W, k, iters).total;
 }
@@ -304,7 +523,7 @@ extern "C" int mfl_meanfield_backward(const float *unary, const float *img, cons
     if ((affine_w != nullptr) != (d_affine_w != nullptr) || (affine_w != nullptr) != (d_affine_b != nullptr))
         return MFL_ERR_INVALID_ARGUMENT;
     if ((compat != nullptr) != (d_compat != nullptr)) return MFL_ERR_INVALID_ARGUMENT;
-    if (C > kMaxC) return MFL_ERR_INVALID_ARGUMENT;           // the pre kernel holds a pixel's channel vectors in registers
+    if (C > kMaxLargeC) return MFL_ERR_INVALID_ARGUMENT;      // the label products hold the matrix in LDS (160 x 160 floats)
     if ((long long)B * C * H * W >= (1LL << 31)) return MFL_ERR_TOO_LARGE;
     const size_t need = mfl::loop_backward_workspace_bytes(B, C, H, W, k, iters);
     if (need == 0) return MFL_ERR_INVALID_ARGUMENT;
@@ -334,7 +553,7 @@ extern "C" int mfl_meanfield_backward(const float *unary, const float *img, cons
         if (rc) return rc;
     }
     const size_t lds = compat ? (size_t)2 * 32 * kPitch * 4 : 0;
-    if (compat) hipLaunchKernelGGL(loop_pad_compat_kernel, dim3(1), dim3(1024), 0, st, compat, ct32, C);
+    if (compat && C <= kMaxC) hipLaunchKernelGGL(loop_pad_compat_kernel, dim3(1), dim3(1024), 0, st, compat, ct32, C);
     // the pre kernel of this call: channel capacity (C rounded up to 8) x affine x label matrix
     using PreKernel = void (*)(const float *, int, const float *, const float *, const float *, const float *, const float *,
                                const float *, const float *, const float *, const float *, const float *, float *, float *, float *,
@@ -348,7 +567,7 @@ extern "C" int mfl_meanfield_backward(const float *unary, const float *img, cons
         if (C <= 8) MFL_PRE_PICK(8);
         else if (C <= 16) MFL_PRE_PICK(16);
         else if (C <= 24) MFL_PRE_PICK(24);
-        else MFL_PRE_PICK(32);
+        else MFL_PRE_PICK(32);      // (more than 32 labels take the split kernels below)
 #undef MFL_PRE_PICK
     }
     const bool split = mfl::local_backward_split_supported(B, C, H, W, k);
@@ -369,11 +588,51 @@ extern "C" int mfl_meanfield_backward(const float *unary, const float *img, cons
         }
         if (rc) return rc;
         const int first = t == iters - 1;
-        hipLaunchKernelGGL(pre, dim3(ws.nblk), dim3(kPix), lds, st, first ? grad_logq : dx, first ? 0 : 1,
-                           logq_all + (size_t)t * n, split ? nullptr : m, xt, psum, qsum, pos_w, col_w, affine_w, affine_b,
-                           (const float *)ct32, dm, dls, d_affine_w, d_affine_b, compat ? part : nullptr, first, B, C, L);
-        if (compat)
-            hipLaunchKernelGGL(loop_compat_reduce_kernel, dim3(C * C), dim3(256), 0, st, part, ws.nblk, C * C, d_compat, first);
+        if (C <= kMaxC) {
+            hipLaunchKernelGGL(pre, dim3(ws.nblk), dim3(kPix), lds, st, first ? grad_logq : dx, first ? 0 : 1,
+                               logq_all + (size_t)t * n, split ? nullptr : m, xt, psum, qsum, pos_w, col_w, affine_w, affine_b,
+                               (const float *)ct32, dm, dls, d_affine_w, d_affine_b, compat ? part : nullptr, first, B, C, L);
+            if (compat)
+                hipLaunchKernelGGL(loop_compat_reduce_kernel, dim3(C * C), dim3(256), 0, st, part, ws.nblk, C * C, d_compat, first);
+        } else {
+            // more than 32 labels: elementwise step, then the two label products as GEMMs, then the affine
+            float *dp = (float *)(base + ws.dp), *abuf = (float *)(base + ws.abuf), *da = (float *)(base + ws.da);
+            const bool aff = affine_w != nullptr, mat = compat != nullptr;
+            // where the gradient of A_t lands: dm directly when nothing follows it
+            float *dp_dst = (!mat && !aff) ? dm : (mat ? dp : da);
+            float *m_dst = split && aff ? m : nullptr;                     // M_t is needed again for the affine's gradient
+            hipLaunchKernelGGL(loop_softmax_grad_kernel, dim3((unsigned)(((size_t)B * L + 255) / 256)), dim3(256), 0, st,
+                               first ? grad_logq : dx, first ? 0 : 1, logq_all + (size_t)t * n, split ? nullptr : m, xt, psum, qsum, pos_w,
+                               col_w, affine_w, affine_b, dp_dst, mat ? abuf : nullptr, m_dst, dls, first, B, C, L);
+            if (mat) {
+                float *da_dst = aff ? da : dm;
+                const long long ntiles = ((long long)B * L + 31) / 32;
+                long long blocks = (ntiles + kMatWaves - 1) / kMatWaves;
+                if (blocks > 256) blocks = 256;
+                const size_t mlds = (size_t)2 * ((C + 1) / 2) * 32 * ws.mb * 4;
+                const long long units = (long long)ws.mb * ws.nsl;
+#define MFL_LARGE_C(MBV)                                                                                                              \
+    case MBV:                                                                                                                         \
+        MFL_CHECK_HIP(hipFuncSetAttribute((const void *)loop_matmul_kernel<MBV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL(loop_matmul_kernel<MBV>, dim3((unsigned)blocks), dim3(64 * kMatWaves), mlds, st, (const float *)dp, compat,   \
+                           da_dst, B, C, L);                                                                                          \
+        hipLaunchKernelGGL(loop_dcompat_kernel<MBV>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, (const float *)dp,             \
+                           (const float *)abuf, part, B, C, L, ws.nsl, ws.tiles_per_slice, ws.tiles_per_image);                         \
+        break;
+                switch (ws.mb) {
+                    MFL_LARGE_C(2) MFL_LARGE_C(3) MFL_LARGE_C(4) MFL_LARGE_C(5)
+                default: return MFL_ERR_INVALID_ARGUMENT;
+                }
+#undef MFL_LARGE_C
+                hipLaunchKernelGGL(loop_dcompat_reduce_kernel, dim3((unsigned)((C * C + 255) / 256)), dim3(256), 0, st, (const float *)part,
+                                   d_compat, C, ws.mb, ws.nsl, first);
+            }
+            if (aff) {
+                const size_t CL = (size_t)C * L;
+                hipLaunchKernelGGL(loop_affine_grad_kernel, dim3((unsigned)((CL + 255) / 256)), dim3(256), 0, st, (const float *)da,
+                                   (const float *)m, affine_w, dm, d_affine_w, d_affine_b, first, B, CL);
+            }
+        }
         MFL_CHECK_HIP(hipGetLastError());
         if (split) {
             rc = mfl::local_backward_apply(xt, img, pos_w, col_w, dm, dx, dpar + 2 * t, B, C, H, W, k, sub, ws.sub_bytes, stream);

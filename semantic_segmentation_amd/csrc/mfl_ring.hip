@@ -562,8 +562,16 @@ ring_kernel(RingGeom rg, int lds_floats, int tail_per_group, const float *__rest
     const size_t wunit = ((size_t)img * g.NBB + beta) * g.NG + gamma_t;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(wtab + wunit * (size_t)(KS * KS) * (Cfg::WQ * 256)), 0, 0x7fffffff, 0x00020000);
+#ifdef MFL_EXP_PAIR
+    // timing experiment (wrong results): the second half of a workgroup's groups walks the records of the first half,
+    // i.e. requests exactly the element lines its partner requests - what a workgroup made of units that read the
+    // same rows of pad(x) at the same time would see; the weights stay each unit's own
+    const int gamma_rec = live ? gb * NGW + (gi % (NGW / 2)) : g.NG - 1;
+#else
+    const int gamma_rec = gamma_t;
+#endif
     Loop<CH, KS, NGW, NCS> loop{acc, rsrc, wrsrc,
-                                (ConstWords)(uintptr_t)(table + ring_record_index(rg, beta, gamma_t, 0, ci)),
+                                (ConstWords)(uintptr_t)(table + ring_record_index(rg, beta, gamma_rec, 0, ci)),
                                 g.NCS * g.RECW, rg.cols_kx, rg.cols_sa, g.gap, lane, ((lane + g.gap) & 63) * 4, 0, {}, {}, {}};
 #ifdef MFL_STAMPS
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();

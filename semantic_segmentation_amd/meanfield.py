@@ -8,7 +8,7 @@ Per iteration (every step is one of the reference's modules, only the loop is ne
     Q_{t+1} = exp(logQ),  Q_0 = U                             AdvancedModel.py:222
 
 The forward is always the fused C-ABI loop.  When a gradient is required, the backward is the library's
-loop backward (recompute with checkpoints, mfl_meanfield_backward) for up to 32 labels; above that the same
+loop backward (recompute with checkpoints, mfl_meanfield_backward) for up to 160 labels; above that the same
 arithmetic is composed per iteration from the HIP local operator (with its HIP backward) and stock
 differentiable torch ops for the normalisation.
 """

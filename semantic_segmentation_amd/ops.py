@@ -94,7 +94,7 @@ def meanfield_forward(unary, image, pos_w, col_w, k, iters, affine_w=None, affin
     return logq
 
 
-MEANFIELD_BACKWARD_MAX_LABELS = 32
+MEANFIELD_BACKWARD_MAX_LABELS = 160
 
 
 def meanfield_forward_iterates(unary, image, pos_w, col_w, k, iters, affine_w=None, affine_b=None, compat=None):

@@ -384,3 +384,49 @@ def test_device_preprocessing_equals_pillow_and_torchvision_arithmetic(S):
     # a batch of images of different sizes in one call
     both = host(S.preprocess.preprocess([d["image0"], d["image1"]], 64, 64))
     assert np.array_equal(both[0], d["tensor0"]) and np.array_equal(both[1], d["tensor1"])
+
+
+# ------------------------------------------------------------------ more than 32 labels
+@pytest.mark.parametrize("shape,iters", [((1, 40, 96, 100, 3), 2), ((2, 70, 100, 90, 5), 2), ((1, 150, 16, 16, 7), 3), ((2, 33, 20, 23, 3), 1)])
+@pytest.mark.parametrize("mode", ["affine+compat", "compat", "affine", "plain"])
+def test_meanfield_backward_many_labels_vs_oracle(shape, iters, mode, S, oracle):
+    """The loop backward above 32 labels (label products on the matrix cores, the local backward block by block of
+    output channels where the image is wide enough for the diagonal kernels) against the oracle's restatement."""
+    B, C, H, W, k = shape
+    unary, img, compat, aw, ab, G = _loop_inputs(shape, 87)
+    compat = compat / 8
+    if "compat" not in mode:
+        compat = None
+    if "affine" not in mode:
+        aw = ab = None
+    opt = lambda a: None if a is None else dev(a)
+    if compat is None and C > 33 and iters > 1:
+        iters = 1          # (the forward loop above 32 labels without a matrix runs unfused; one iteration covers the backward)
+    du, dpar, daw, dab, dcompat = S.ops.meanfield_backward(dev(unary), dev(img), scalar(-0.004), scalar(-0.003), k, iters, dev(G),
+                                                           opt(aw), opt(ab), opt(compat))
+    ref = oracle.meanfield_backward(unary, img, -0.004, -0.003, k, iters, G, aw, ab, compat)
+    assert_close(host(du), ref["dU"], RTOL, "dU")
+    if compat is not None:
+        assert_close(host(dcompat), ref["dcompat"], RTOL, "dcompat")
+    if aw is not None:
+        assert_close(host(daw).reshape(C, H, W), ref["daw"], RTOL, "d affine w")
+        assert_close(host(dab).reshape(C, H, W), ref["dab"], RTOL, "d affine b")
+    # (sums of C*L*K signed terms that largely cancel on the small shapes: the floor is the bar the local operator's test uses)
+    assert abs(float(dpar[0]) - ref["dpw"]) <= 2e-4 * abs(ref["dpw"]) + 1e-5
+    assert abs(float(dpar[1]) - ref["dcw"]) <= 2e-4 * abs(ref["dcw"]) + 1e-5
+    again = S.ops.meanfield_backward(dev(unary), dev(img), scalar(-0.004), scalar(-0.003), k, iters, dev(G), opt(aw), opt(ab), opt(compat))
+    if W >= 64 + k:           # the diagonal kernels' order-free scatter: the whole gradient is reproducible bit for bit
+        assert torch.equal(again[0], du)
+
+
+def test_local_backward_many_labels_bitwise_reproducible(S, oracle):
+    """More than 33 labels on an image the diagonal kernels take: the backward runs block by block of output channels
+    with the fixed-point scatter; equal to the oracle and bit for bit between two runs."""
+    shape = (2, 70, 100, 90, 5)
+    x, img, dy = make_inputs(shape, 89)
+    a = S.ops.local_backward(dev(x), scalar(0.3), scalar(-0.7), 5, dev(dy), image=dev(img))
+    b = S.ops.local_backward(dev(x), scalar(0.3), scalar(-0.7), 5, dev(dy), image=dev(img))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    rdx, rdpw, rdcw = oracle.local_backward(x, 0.3, -0.7, 5, dy, img=img)
+    assert_close(host(a[0]), rdx, RTOL, "dx")
+    assert abs(float(a[1][0]) - rdpw) <= 2e-4 * abs(rdpw) and abs(float(a[1][1]) - rdcw) <= 2e-4 * abs(rdcw)

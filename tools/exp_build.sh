@@ -4,7 +4,7 @@
 # usage: tools/exp_build.sh tag "-DFLAG ..." [tag flags ...]
 cd "$(dirname "$0")/../semantic_segmentation_amd/csrc"
 CH=${EXP_CH:-7}; KS=${EXP_KS:-11}
-OTHERS=$(ls build/mfl_gather_*.o build/mfl_diag_*.o build/mfl_ring_*.o build/mfl_loop_backward.o build/mfl_label_step.o build/mfl_label_context.o | grep -v mfl_ring_${CH}_${KS}.o)
+OTHERS=$(ls build/mfl_gather_*.o build/mfl_diag_*.o build/mfl_ring_*.o build/mfl_loop_backward.o build/mfl_label_step.o build/mfl_label_context.o build/mfl_preprocess.o | grep -v mfl_ring_${CH}_${KS}.o)
 CC="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function"
 while [ $# -ge 2 ]; do
   tag=$1; flags=$2; shift 2
