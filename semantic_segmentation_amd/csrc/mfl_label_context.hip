@@ -56,6 +56,7 @@ constexpr int kWavesPerGroup = 4;
 template <int MODE>
 struct TilesPerWave { static constexpr int value = MODE == 1 ? 4 : 1; };
 constexpr int kChunk = 32;          // K-values of the weights per LDS stage (even)
+constexpr int kMaxMixtures = 5;     // mixtures per label (the entry points reject more)
 constexpr int kAhead = 4;           // k-steps whose activation loads are in flight together
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -80,15 +81,16 @@ __global__ void label_context_activation_kernel(const float *__restrict__ t, con
 
 // w2[kk][32 m + l] = conv_w[m*L + l][kk] (kk = (c*k + ky)*k + kx as stored), zero for l >= L and for the padded
 // K-values kk >= KK; koff[kk] = offset of tap kk in the padded planes (0 for padded K-values)
+// packed: rows r = output channel m*L + l itself, R = 32 * ceil(L*M / 32) (fewer zero rows when L is not 32)
 __global__ void label_context_weights_kernel(const float *__restrict__ conv_w, float *__restrict__ w2, int *__restrict__ koff,
-                                             int L, int M, int ks, int KK, int KKp, int plane, int Wp)
+                                             int L, int M, int ks, int KK, int KKp, int plane, int Wp, int R, int packed)
 {
-    const int R = 32 * M;
     const size_t n = (size_t)KKp * R;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int kk = (int)(i / R), r = (int)(i - (size_t)kk * R);
         const int m = r >> 5, l = r & 31;
-        w2[i] = (l < L && kk < KK) ? conv_w[((size_t)(m * L + l)) * KK + kk] : 0.f;
+        if (packed) w2[i] = (r < L * M && kk < KK) ? conv_w[(size_t)r * KK + kk] : 0.f;
+        else w2[i] = (l < L && kk < KK) ? conv_w[((size_t)(m * L + l)) * KK + kk] : 0.f;
         if (r == 0) {
             int off = 0;
             if (kk < KK) {
@@ -103,20 +105,24 @@ __global__ void label_context_weights_kernel(const float *__restrict__ conv_w, f
 // MODE 0: the fused forward epilogue (optionally keeping the arg-min mixture `amin` and the convolution's value
 //         there `cmin`, for the backward)
 // MODE 1: plain convolution: out[b][l][y][x] = accumulator (M = 1), written to `smooth`
+// MODE 2: the fused forward with packed rows: M counts blocks of 32 rows, row r = output channel r; the mixtures of a
+//         label then sit in different lanes and registers, so the accumulators pass through a per-wave LDS tile
+//         before the min over the `mixtures` mixtures.  21 labels x 5 mixtures: 4 blocks instead of 5.
 // Cin: channels of the padded input planes (L for the forward; L*M for the data gradient, whose rows are the L labels)
+// (two waves per SIMD: the epilogue of one overlaps the matrix instructions of the other)
 template <int M, int MODE>
-__global__ void __launch_bounds__(64 * kWavesPerGroup)
+__global__ void __launch_bounds__(64 * kWavesPerGroup, 2)
 label_context_kernel(const float *__restrict__ apad, const float *__restrict__ w2, const int *__restrict__ koff,
                      const float *__restrict__ conv_b, const float *__restrict__ ga_w, const float *__restrict__ ga_b,
                      const float *__restrict__ unary, float *__restrict__ smooth, float *__restrict__ logq,
                      unsigned char *__restrict__ amin, float *__restrict__ cmin, int B, int L, int Cin, int H,
-                     int W, int Wp, int plane, int KKp, int tiles_per_row)
+                     int W, int Wp, int plane, int KKp, int tiles_per_row, int mixtures)
 {
     constexpr int R = 32 * M;
     constexpr int kTilesPerWave = TilesPerWave<MODE>::value;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *wl = lds;                                           // [kChunk][R]
-    int *ko = reinterpret_cast<int *>(lds + kChunk * R);       // [KKp]
+    // two stages of weights [2][kChunk][R], then the tap offsets [KKp]
+    int *ko = reinterpret_cast<int *>(lds + 2 * kChunk * R);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = lane & 31, h = lane >> 5;
     const int HW = H * W;
@@ -124,15 +130,19 @@ label_context_kernel(const float *__restrict__ apad, const float *__restrict__ w
     // this wave's tiles: 32 consecutive pixels of an image row each (the last tile of a row may run past
     // the row's end: those lanes compute on clamped pixels and store nothing)
     const long long ntiles = (long long)B * H * tiles_per_row;
-    long long tile0 = ((long long)blockIdx.x * kWavesPerGroup + wave) * kTilesPerWave;
+    // Tile order: the images of one tile position are consecutive, and each XCD (workgroups are dealt to the 8 XCDs
+    // round robin) takes a contiguous range of positions: the affine's planes, shared by the images, and the rows that
+    // vertically adjacent tiles share are then read through one XCD's L2.
+    const long long wg = (long long)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+    long long tile0 = (wg * kWavesPerGroup + wave) * kTilesPerWave;
     int base[kTilesPerWave], pixl[kTilesPerWave], img[kTilesPerWave];
     bool ok[kTilesPerWave];
 #pragma unroll
     for (int tt = 0; tt < kTilesPerWave; ++tt) {
         const long long tile = tile0 + tt < ntiles ? tile0 + tt : ntiles - 1;
-        const int tx = (int)(tile % tiles_per_row);
-        const long long ry = tile / tiles_per_row;
-        const int y = (int)(ry % H), b = (int)(ry / H);
+        const int b = (int)(tile % B);
+        const long long pos = tile / B;
+        const int tx = (int)(pos % tiles_per_row), y = (int)(pos / tiles_per_row);
         const int x = tx * 32 + p;
         ok[tt] = tile0 + tt < ntiles && x < W;
         const int xc = x < W ? x : W - 1;
@@ -148,35 +158,89 @@ label_context_kernel(const float *__restrict__ apad, const float *__restrict__ w
 #pragma unroll
             for (int v = 0; v < 16; ++v) d[tt][m][v] = 0.f;
 
-    for (int k0 = 0; k0 < KKp; k0 += kChunk) {
-        __syncthreads();                                       // the previous chunk's readers are done (first pass: ko is complete)
+    // Software pipeline: the weights of chunk c + 1 travel global -> registers while chunk c is multiplied and reach
+    // the other LDS stage after it (one barrier per chunk); the activations of group g + 1 (kAhead k-steps) are
+    // loaded before the matrix instructions of group g.
+    constexpr int kGroups = kChunk / (2 * kAhead);             // per chunk (even: the two activation buffers alternate)
+    static_assert(kGroups % 2 == 0, "activation double buffer");
+    constexpr int WPT = kChunk * R / 4 / (64 * kWavesPerGroup); // float4 pieces of a weight stage per thread
+    static_assert(kChunk * R / 4 % (64 * kWavesPerGroup) == 0, "weight stage");
+    const int nchunks = KKp / kChunk;
+    float4 wr[WPT];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(w2);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) dst[threadIdx.x + i * 64 * kWavesPerGroup] = src[threadIdx.x + i * 64 * kWavesPerGroup];
+    }
+    __syncthreads();                                           // stage 0 and the tap offsets are complete
+    float bv[2][kAhead][kTilesPerWave];
+#pragma unroll
+    for (int jj = 0; jj < kAhead; ++jj) {
+        const int off = ko[2 * jj + h];
+#pragma unroll
+        for (int tt = 0; tt < kTilesPerWave; ++tt) bv[0][jj][tt] = apad[base[tt] + off];
+    }
+    for (int c = 0; c < nchunks; ++c) {
+        // (the last pass fetches and stages its own chunk again rather than branch: nothing reads that stage)
+        const int cn = c + 1 < nchunks ? c + 1 : c;
         {
-            const float4 *src = reinterpret_cast<const float4 *>(w2 + (size_t)k0 * R);
-            float4 *dst = reinterpret_cast<float4 *>(wl);
-            for (int i = threadIdx.x; i < kChunk * R / 4; i += blockDim.x) dst[i] = src[i];
+            const float4 *src = reinterpret_cast<const float4 *>(w2 + (size_t)cn * kChunk * R);
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) wr[i] = src[threadIdx.x + i * 64 * kWavesPerGroup];
         }
-        __syncthreads();
-        for (int j0 = 0; j0 < kChunk / 2; j0 += kAhead) {
-            float bv[kAhead][kTilesPerWave];
+        const float *wl = lds + (c & 1) * kChunk * R;
+#pragma unroll
+        for (int gg = 0; gg < kGroups; ++gg) {
+            int knext = c * kChunk + (gg + 1) * 2 * kAhead;
+            if (knext >= KKp) knext = 0;                       // (past the end: any valid group, unused)
 #pragma unroll
             for (int jj = 0; jj < kAhead; ++jj) {
-                const int off = ko[k0 + 2 * (j0 + jj) + h];
+                const int off = ko[knext + 2 * jj + h];
 #pragma unroll
-                for (int tt = 0; tt < kTilesPerWave; ++tt) bv[jj][tt] = apad[base[tt] + off];
+                for (int tt = 0; tt < kTilesPerWave; ++tt) {
+#ifdef MFL_EXP_NOB
+                    bv[(gg + 1) & 1][jj][tt] = __builtin_bit_cast(float, off + base[tt]);
+#else
+                    bv[(gg + 1) & 1][jj][tt] = apad[base[tt] + off];
+#endif
+                }
             }
 #pragma unroll
             for (int jj = 0; jj < kAhead; ++jj) {
-                const float *row = wl + (2 * (j0 + jj) + h) * R + p;
+                const float *row = wl + (2 * (gg * kAhead + jj) + h) * R + p;
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
+#ifdef MFL_EXP_NOA
+                    const float a = __builtin_bit_cast(float, (int)(row - lds) + m);
+#else
                     const float a = row[32 * m];
+#endif
 #pragma unroll
                     for (int tt = 0; tt < kTilesPerWave; ++tt)
-                        d[tt][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[jj][tt], d[tt][m], 0, 0, 0);
+                        d[tt][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[gg & 1][jj][tt], d[tt][m], 0, 0, 0);
                 }
             }
         }
+        {
+            float4 *dst = reinterpret_cast<float4 *>(lds + ((c + 1) & 1) * kChunk * R);
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) dst[threadIdx.x + i * 64 * kWavesPerGroup] = wr[i];
+        }
+        __syncthreads();                                       // stage (c + 1) & 1 is complete; stage c & 1 may be overwritten
     }
+#ifdef MFL_EXP_NOEPI
+    if (MODE != 1) {
+        float acc = 0.f;
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc += d[0][m][v];
+        float *dst = logq ? logq : smooth;
+        if (ok[0] && h == 0 && dst) dst[(size_t)img[0] * L * HW + pixl[0]] = acc;
+        return;
+    }
+#endif
 
     if constexpr (MODE == 1) {
 #pragma unroll
@@ -199,6 +263,50 @@ label_context_kernel(const float *__restrict__ apad, const float *__restrict__ w
         float sm[16];
         float mu = -INFINITY;
         float u[16];
+        if constexpr (MODE == 2) {
+            // rows r = output channel: all accumulators pass through this wave's LDS tile [32 M rows][32 pixels] (it reuses
+            // the weight stages: every wave has passed the loop's last barrier), and a lane collects the mixtures of its
+            // labels from there.  The loop over the mixtures is unrolled to the maximum with the index clamped (a repeated
+            // mixture never wins the strict comparison), so that the loads of the affine's planes are independent of any
+            // branch and in flight together.
+            float *tile = lds + wave * (R * 32);
+            float cvat[16];
+            int mat[16];
+#pragma unroll
+            for (int nb = 0; nb < M; ++nb)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) tile[(32 * nb + 8 * (v / 4) + 4 * h + (v % 4)) * 32 + p] = d[tt][nb][v];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int l = 8 * (v / 4) + 4 * h + (v % 4);
+                const int lc = l < L ? l : L - 1;
+#pragma unroll
+                for (int m = 0; m < kMaxMixtures; ++m) {
+                    const int mc = m < mixtures ? m : mixtures - 1;
+                    const int oc = mc * L + lc;
+                    const float cv = tile[oc * 32 + p] + (conv_b ? conv_b[oc] : 0.f);
+                    float c = cv;
+                    if (ga_w) c = fmaf(ga_w[(size_t)oc * HW + l0], c, ga_b[(size_t)oc * HW + l0]);
+                    // (mixtures arrive in increasing m: the first minimum wins, as torch.min(dim))
+                    if (m == 0 || c < sm[v]) { sm[v] = c; mat[v] = mc; cvat[v] = cv; }
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int l = 8 * (v / 4) + 4 * h + (v % 4);
+                const bool valid = l < L;
+                const int lc = valid ? l : L - 1;
+                if (amin && valid && ok[tt]) {
+                    const size_t o = ((size_t)img[tt] * L + lc) * HW + l0;
+                    amin[o] = (unsigned char)mat[v];
+                    cmin[o] = cvat[v];
+                }
+                u[v] = valid ? unary[((size_t)img[tt] * L + lc) * HW + l0] : -INFINITY;
+                mu = fmaxf(mu, u[v]);
+            }
+        } else {
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int l = 8 * (v / 4) + 4 * h + (v % 4);
@@ -222,6 +330,7 @@ label_context_kernel(const float *__restrict__ apad, const float *__restrict__ w
             }
             u[v] = valid ? unary[((size_t)img[tt] * L + lc) * HW + l0] : -INFINITY;
             mu = fmaxf(mu, u[v]);
+        }
         }
         mu = fmaxf(mu, other_half(mu));
         float su = 0.f;
@@ -376,78 +485,160 @@ context_affine_grad_kernel(const float *__restrict__ da, const float *__restrict
     if (la_w) { d_la_w[i] = sw; d_la_b[i] = sb; }
 }
 
-// Weight gradient: D[row][col] = sum over pixels of g[row][pixel] * a[col][pixel], rows r = 32 m + l (gradient plane
-// m*L + l), columns = 32 consecutive taps kk = (i*ks + ky)*ks + kx of one column block: a[col][pixel] is the padded
-// activation plane i shifted by (ky, kx).  One wave per (column block, pixel slice); a slice is a run of row tiles
-// (64 consecutive pixels of one image row).  Per matrix instruction lane (p, h) supplies row / column p at pixel
-// x0 + 32 h + j: every lane walks 32 consecutive floats of its own plane row, four at a time.  The gradient planes
-// have a row pitch that covers the last, partial tile of an image row with zeros; what the activation planes hold
-// there is multiplied by those zeros.
+// Weight gradient: D[row][col] = sum over pixels of g[row][pixel] * a[col][pixel], rows r = output channel (gradient plane
+// r; NB blocks of 32 rows), columns = taps kk = (i*ks + ky)*ks + kx: a[col][pixel] is the padded activation plane i
+// shifted by (ky, kx).  A workgroup of four waves takes four consecutive column blocks (one per wave) over a slice of
+// row tiles (64 consecutive pixels of one image row) and stages every tile through LDS with coalesced loads:
+//   As[row][64]       the tile of all L*M gradient planes (every wave multiplies the same rows)
+//   Bs[(i, ky)][64 + ks - 1]   the activation rows the workgroup's 128 columns read; column (i, ky, kx) is row (i, ky)
+//                     shifted by kx
+// and prefetches the next tile into registers while the matrix instructions of the current one run.  Per matrix
+// instruction lane (p, h) supplies row / column p at pixel 32 h + j of the tile.  The gradient planes have a row pitch
+// that covers the last, partial tile of an image row with zeros; what the activation planes hold there is multiplied
+// by those zeros.  (A first version let every lane stream its own plane row from global memory: 25 ms at 21 labels,
+// 5 mixtures, 512 x 512, batch 8, bound by the 64 cache lines each such load touches.)
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f4a __attribute__((ext_vector_type(4)));
 
-template <int M>
+constexpr int kWgPitchA = 68;            // floats per As row: 16-byte aligned, lanes p = 0 .. 7 of a 16-byte read cover all banks
+
+template <int NB>
 __global__ void __launch_bounds__(64 * kWavesPerGroup)
-context_wgrad_kernel(const float *__restrict__ gpad, const float *__restrict__ apad, const int *__restrict__ koff,
-                     float *__restrict__ part, int B, int L, int H, int W, int p, int Wp, int plane, int WpG, int gplane,
-                     int ncb, int nsl, int tiles_per_slice, int tiles_per_row)
+context_wgrad_kernel(const float *__restrict__ gpad, const float *__restrict__ apad, float *__restrict__ part, int B, int L, int LM,
+                     int H, int W, int ks, int Wp, int plane, int WpG, int gplane, int KK, int ncb, int ncbg, int nsl,
+                     int tiles_per_slice, int tiles_per_row, int brows, int bpitch)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *As = lds;                                   // [NB * 32][kWgPitchA]
+    float *Bs = lds + NB * 32 * kWgPitchA;             // [brows][bpitch]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 31, h = lane >> 5;
-    const long long unit = (long long)blockIdx.x * kWavesPerGroup + wave;
-    if (unit >= (long long)ncb * nsl) return;
-    const int cb = (int)(unit % ncb), sl = (int)(unit / ncb);
+    const int p = ks / 2;
+    const int cbg = blockIdx.x % ncbg, sl = blockIdx.x / ncbg;
+    const int cb = cbg * kWavesPerGroup + wave;
     const long long ntiles = (long long)B * H * tiles_per_row;
     const long long t0 = (long long)sl * tiles_per_slice;
     const long long t1 = t0 + tiles_per_slice < ntiles ? t0 + tiles_per_slice : ntiles;
-    const int coff = koff[cb * 32 + pl];                 // this lane's column: plane and tap offset in the activation planes
-    const bool row_ok = pl < L;
-    f16v d[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) d[m][v] = 0.f;
-    for (long long tile = t0; tile < t1; ++tile) {
+    // the activation rows (i, ky) = divmod(rowid, ks) this workgroup's columns read: rowid in [r0, r0 + brows)
+    const int nrow_all = L * ks;
+    const int r0 = (cbg * kWavesPerGroup * 32) / ks;
+    // this lane's column
+    int kk = cb * 32 + pl;
+    if (kk >= KK) kk = KK - 1;                          // (padded columns: any valid one, their sums are dropped)
+    const int boff = (kk / ks - r0) * bpitch + kk % ks + 32 * h;
+    // cooperative loads: As in float4 pieces (row, 16 per row), Bs likewise (row, bpitch / 4 per row)
+    constexpr int APT = (NB * 32 * 16 + 64 * kWavesPerGroup - 1) / (64 * kWavesPerGroup);
+    const int bq = bpitch / 4;
+    const int nbv = brows * bq;                         // float4 pieces of Bs
+    constexpr int BPT = 4;                              // prefetched pieces per thread; windows under 3 taps need more and load in place
+    const bool direct = nbv > BPT * 64 * kWavesPerGroup;
+    f4u ra[APT], rb[BPT];
+    auto fetch = [&](long long tile) {
         const int tx = (int)(tile % tiles_per_row);
         const long long ry = tile / tiles_per_row;
         const int y = (int)(ry % H), b = (int)(ry / H);
-        const int x = tx * 64 + 32 * h;
-        const float *arow = apad + (size_t)b * L * plane + (size_t)y * Wp + x + coff;
-        const float *grow = gpad + ((size_t)b * L * M + (row_ok ? pl : 0)) * gplane + (size_t)(y + p) * WpG + x + p;
+        const int x0 = tx * 64;
+        const float *gb = gpad + (size_t)b * LM * gplane + (size_t)(y + p) * WpG + x0 + p;
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int idx = tid + i * 64 * kWavesPerGroup;
+            const int row = idx >> 4, c4 = idx & 15;
+            ra[i] = row < LM ? *reinterpret_cast<const f4u *>(gb + (size_t)row * gplane + 4 * c4) : f4u{0.f, 0.f, 0.f, 0.f};
+        }
+        const float *ab = apad + (size_t)b * L * plane + (size_t)y * Wp + x0;
+        if (direct) return;
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            const int idx = tid + i * 64 * kWavesPerGroup;
+            rb[i] = f4u{0.f, 0.f, 0.f, 0.f};
+            if (idx < nbv) {
+                const int row = idx / bq, c4 = idx - row * bq;
+                int rid = r0 + row;
+                if (rid >= nrow_all) rid = nrow_all - 1;
+                const int ci = rid / ks, ky = rid - ci * ks;
+                rb[i] = *reinterpret_cast<const f4u *>(ab + (size_t)ci * plane + (size_t)ky * Wp + 4 * c4);
+            }
+        }
+    };
+    auto stage = [&](long long tile) {
+        if (direct) {
+            const int tx = (int)(tile % tiles_per_row);
+            const long long ry = tile / tiles_per_row;
+            const int y = (int)(ry % H), b = (int)(ry / H);
+            const float *ab = apad + (size_t)b * L * plane + (size_t)y * Wp + tx * 64;
+            for (int idx = tid; idx < nbv; idx += 64 * kWavesPerGroup) {
+                const int row = idx / bq, c4 = idx - row * bq;
+                int rid = r0 + row;
+                if (rid >= nrow_all) rid = nrow_all - 1;
+                const int ci = rid / ks, ky = rid - ci * ks;
+                *reinterpret_cast<f4a *>(Bs + row * bpitch + 4 * c4) =
+                    *reinterpret_cast<const f4u *>(ab + (size_t)ci * plane + (size_t)ky * Wp + 4 * c4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int idx = tid + i * 64 * kWavesPerGroup;
+            const int row = idx >> 4, c4 = idx & 15;
+            if (row < NB * 32) *reinterpret_cast<f4a *>(As + row * kWgPitchA + 4 * c4) = ra[i];
+        }
+        if (!direct) {
+#pragma unroll
+            for (int i = 0; i < BPT; ++i) {
+                const int idx = tid + i * 64 * kWavesPerGroup;
+                if (idx < nbv) {
+                    const int row = idx / bq, c4 = idx - row * bq;
+                    *reinterpret_cast<f4a *>(Bs + row * bpitch + 4 * c4) = rb[i];
+                }
+            }
+        }
+    };
+    f16v d[NB];
+#pragma unroll
+    for (int m = 0; m < NB; ++m)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) d[m][v] = 0.f;
+    if (t0 < t1) fetch(t0);
+    for (long long tile = t0; tile < t1; ++tile) {
+        __syncthreads();                                // the previous tile's readers are done
+        stage(tile);
+        __syncthreads();
+        if (tile + 1 < t1) fetch(tile + 1);             // in flight while this tile is multiplied
+        const float *arow = As + pl * kWgPitchA + 32 * h;
+        const float *brow = Bs + boff;
 #pragma unroll 2
         for (int j = 0; j < 32; j += 4) {
-            const f4u bv = *reinterpret_cast<const f4u *>(arow + j);
-            f4u av[M];
+            float bv[4];
 #pragma unroll
-            for (int m = 0; m < M; ++m) {
-                av[m] = *reinterpret_cast<const f4u *>(grow + (size_t)m * L * gplane + j);
-                if (!row_ok) av[m] = f4u{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int q = 0; q < 4; ++q) bv[q] = brow[j + q];
+            f4a av[NB];
+#pragma unroll
+            for (int m = 0; m < NB; ++m) av[m] = *reinterpret_cast<const f4a *>(arow + m * 32 * kWgPitchA + j);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int m = 0; m < M; ++m) d[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][q], bv[q], d[m], 0, 0, 0);
+                for (int m = 0; m < NB; ++m) d[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][q], bv[q], d[m], 0, 0, 0);
         }
     }
+    if (cb >= ncb) return;
     // register v of lane (p, h): row 8 (v/4) + 4 h + v%4, column p
-    float *out = part + ((size_t)sl * ncb + cb) * (size_t)(M * 1024);
+    float *out = part + ((size_t)sl * ncb + cb) * (size_t)(NB * 1024);
 #pragma unroll
-    for (int m = 0; m < M; ++m)
+    for (int m = 0; m < NB; ++m)
 #pragma unroll
         for (int v = 0; v < 16; ++v) out[m * 1024 + (8 * (v / 4) + 4 * h + (v % 4)) * 32 + pl] = d[m][v];
 }
 
-// d conv_w[m*L + l][kk] = sum over the slices (in order) of part[slice][kk / 32][m][l][kk % 32]
+// d conv_w[oc][kk] = sum over the slices (in order) of part[slice][kk / 32][oc / 32][oc % 32][kk % 32]  (NB blocks of rows)
 __global__ void __launch_bounds__(256)
-context_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ d_conv_w, int L, int M, int KK, int ncb, int nsl)
+context_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ d_conv_w, int LM, int NB, int KK, int ncb, int nsl)
 {
-    const size_t n = (size_t)L * M * KK;
+    const size_t n = (size_t)LM * KK;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const int kk = (int)(idx % KK), oc = (int)(idx / KK);
-    const int m = oc / L, l = oc - m * L;
-    const size_t at = ((size_t)(kk >> 5) * M + m) * 1024 + l * 32 + (kk & 31);
+    const size_t at = ((size_t)(kk >> 5) * NB + (oc >> 5)) * 1024 + (oc & 31) * 32 + (kk & 31);
     float s = 0.f;
-    for (int sl = 0; sl < nsl; ++sl) s += part[(size_t)sl * ncb * (M * 1024) + at];
+    for (int sl = 0; sl < nsl; ++sl) s += part[(size_t)sl * ncb * (NB * 1024) + at];
     d_conv_w[idx] = s;
 }
 
@@ -488,7 +679,7 @@ ContextWorkspace context_carve(int B, int L, int M, int H, int W, int ks, bool b
         w.da = take(n * 4);
         w.ncb = w.KKp / 32;
         const long long ntiles = (long long)B * H * ((W + 63) / 64);
-        long long nsl = kWgradWaves / w.ncb;
+        long long nsl = kWgradWaves / ((w.ncb + kWavesPerGroup - 1) / kWavesPerGroup * kWavesPerGroup);
         if (nsl < 1) nsl = 1;
         if (nsl > ntiles) nsl = ntiles;
         w.tiles_per_slice = (int)((ntiles + nsl - 1) / nsl);
@@ -505,19 +696,23 @@ bool context_supported(int L, int M, int ks) { return L >= 1 && L <= 32 && M >= 
 template <int M, int MODE>
 int launch(const float *planes, const float *w2, const int *koff, int KKp, int Cin, int Wp, int plane, const float *conv_b,
            const float *ga_w, const float *ga_b, const float *unary, float *smooth, float *logq, unsigned char *amin, float *cmin,
-           int B, int L, int H, int W, hipStream_t st)
+           int B, int L, int H, int W, hipStream_t st, int mixtures = M)
 {
     const int tiles_per_row = (W + 31) / 32;
     const long long ntiles = (long long)B * H * tiles_per_row;
     constexpr int kTilesPerWave = TilesPerWave<MODE>::value;
-    const long long groups = (ntiles + kWavesPerGroup * kTilesPerWave - 1) / (kWavesPerGroup * kTilesPerWave);
+    long long groups = (ntiles + kWavesPerGroup * kTilesPerWave - 1) / (kWavesPerGroup * kTilesPerWave);
+    groups = (groups + 7) / 8 * 8;                      // (the kernel deals contiguous ranges to the 8 XCDs)
     if (groups >= (1LL << 31)) return MFL_ERR_TOO_LARGE;
-    const size_t lds = (size_t)kChunk * 32 * M * 4 + (size_t)KKp * 4;
+    // two weight stages and the tap offsets (MODE 2: or, if larger, one [32 M][32] tile per wave for the epilogue's
+    // regrouping of the rows, which reuses that space)
+    size_t lds = (size_t)2 * kChunk * 32 * M * 4 + (size_t)KKp * 4;
+    if (MODE == 2 && lds < (size_t)kWavesPerGroup * 32 * M * 32 * 4) lds = (size_t)kWavesPerGroup * 32 * M * 32 * 4;
     if (lds > 160 * 1024) return MFL_ERR_INVALID_ARGUMENT;
     // (the attribute belongs to the current device's copy of the kernel: set before every launch)
     MFL_CHECK_HIP(hipFuncSetAttribute((const void *)label_context_kernel<M, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL((label_context_kernel<M, MODE>), dim3((unsigned)groups), dim3(64 * kWavesPerGroup), lds, st, planes, w2, koff,
-                       conv_b, ga_w, ga_b, unary, smooth, logq, amin, cmin, B, L, Cin, H, W, Wp, plane, KKp, tiles_per_row);
+                       conv_b, ga_w, ga_b, unary, smooth, logq, amin, cmin, B, L, Cin, H, W, Wp, plane, KKp, tiles_per_row, mixtures);
     return (int)hipGetLastError();
 }
 
@@ -533,13 +728,27 @@ int context_forward(const ContextWorkspace &ws, char *base, const float *t, cons
     const unsigned g1 = (unsigned)((n + 255) / 256 < 65535u * 8u ? (n + 255) / 256 : 65535u * 8u);
     hipLaunchKernelGGL(label_context_activation_kernel, dim3(g1), dim3(256), 0, st, t, la_w, la_b, apad, B, L, H, W, ws.Hp, ws.Wp,
                        ks / 2);
-    const size_t nw = (size_t)ws.KKp * 32 * M;
+    // rows of the GEMM: 32 per mixture (the min over the mixtures is then register-wise), or, where that saves a block of
+    // 32 rows, the output channels packed (21 labels x 5 mixtures: 4 blocks instead of 5)
+    const int nblk = (L * M + 31) / 32;
+    const bool packed = nblk < M;
+    const int R = 32 * (packed ? nblk : M);
+    const size_t nw = (size_t)ws.KKp * R;
     hipLaunchKernelGGL(label_context_weights_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, conv_w,
-                       (float *)(base + ws.w2), (int *)(base + ws.koff), L, M, ks, ws.KK, ws.KKp, ws.Hp * ws.Wp, ws.Wp);
+                       (float *)(base + ws.w2), (int *)(base + ws.koff), L, M, ks, ws.KK, ws.KKp, ws.Hp * ws.Wp, ws.Wp, R, packed ? 1 : 0);
     MFL_CHECK_HIP(hipGetLastError());
     const float *w2 = (const float *)(base + ws.w2);
     const int *koff = (const int *)(base + ws.koff);
     const int plane = ws.Hp * ws.Wp;
+    if (packed) {
+#define MFL_CTX_PACKED(NB) \
+    case NB: return launch<NB, 2>(apad, w2, koff, ws.KKp, L, ws.Wp, plane, conv_b, ga_w, ga_b, unary, smooth, logq, amin, cmin, B, L, H, W, st, M);
+        switch (nblk) {
+            MFL_CTX_PACKED(1) MFL_CTX_PACKED(2) MFL_CTX_PACKED(3) MFL_CTX_PACKED(4)
+        default: return MFL_ERR_INVALID_ARGUMENT;
+        }
+#undef MFL_CTX_PACKED
+    }
 #define MFL_CTX_FWD(MV) \
     case MV: return launch<MV, 0>(apad, w2, koff, ws.KKp, L, ws.Wp, plane, conv_b, ga_w, ga_b, unary, smooth, logq, amin, cmin, B, L, H, W, st);
     switch (M) {
@@ -549,14 +758,19 @@ int context_forward(const ContextWorkspace &ws, char *base, const float *t, cons
 #undef MFL_CTX_FWD
 }
 
-template <int M>
-void launch_wgrad(const ContextWorkspace &ws, char *base, int B, int L, int H, int W, int ks, hipStream_t st)
+template <int NB>
+int launch_wgrad(const ContextWorkspace &ws, char *base, int B, int L, int LM, int H, int W, int ks, hipStream_t st)
 {
-    const long long units = (long long)ws.ncb * ws.nsl;
-    hipLaunchKernelGGL(context_wgrad_kernel<M>, dim3((unsigned)((units + kWavesPerGroup - 1) / kWavesPerGroup)), dim3(64 * kWavesPerGroup), 0,
-                       st, (const float *)(base + ws.gpad), (const float *)(base + ws.apad), (const int *)(base + ws.koff),
-                       (float *)(base + ws.part), B, L, H, W, ks / 2, ws.Wp, ws.Hp * ws.Wp, ws.WpG, ws.HpG * ws.WpG, ws.ncb, ws.nsl,
-                       ws.tiles_per_slice, (W + 63) / 64);
+    const int ncbg = (ws.ncb + kWavesPerGroup - 1) / kWavesPerGroup;
+    const int brows = (kWavesPerGroup * 32) / ks + 2;
+    const int bpitch = (64 + ks - 1 + 3) / 4 * 4 + 4;
+    const size_t lds = ((size_t)NB * 32 * kWgPitchA + (size_t)brows * bpitch) * 4;
+    MFL_CHECK_HIP(hipFuncSetAttribute((const void *)context_wgrad_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(context_wgrad_kernel<NB>, dim3((unsigned)((long long)ncbg * ws.nsl)), dim3(64 * kWavesPerGroup), lds, st,
+                       (const float *)(base + ws.gpad), (const float *)(base + ws.apad), (float *)(base + ws.part), B, L, LM, H, W, ks,
+                       ws.Wp, ws.Hp * ws.Wp, ws.WpG, ws.HpG * ws.WpG, ws.KK, ws.ncb, ncbg, ws.nsl, ws.tiles_per_slice, (W + 63) / 64,
+                       brows, bpitch);
+    return (int)hipGetLastError();
 }
 
 }  // namespace
@@ -660,17 +874,19 @@ extern "C" int mfl_label_context_backward(const float *t, const float *la_w, con
         }
     }
     // weight gradient
-    switch (M) {
-    case 1: launch_wgrad<1>(ws, base, B, L, H, W, ks, st); break;
-    case 2: launch_wgrad<2>(ws, base, B, L, H, W, ks, st); break;
-    case 3: launch_wgrad<3>(ws, base, B, L, H, W, ks, st); break;
-    case 4: launch_wgrad<4>(ws, base, B, L, H, W, ks, st); break;
-    default: launch_wgrad<5>(ws, base, B, L, H, W, ks, st); break;
+    const int nb = (LM + 31) / 32;               // blocks of 32 rows (output channels packed)
+    switch (nb) {
+    case 1: rc = launch_wgrad<1>(ws, base, B, L, LM, H, W, ks, st); break;
+    case 2: rc = launch_wgrad<2>(ws, base, B, L, LM, H, W, ks, st); break;
+    case 3: rc = launch_wgrad<3>(ws, base, B, L, LM, H, W, ks, st); break;
+    case 4: rc = launch_wgrad<4>(ws, base, B, L, LM, H, W, ks, st); break;
+    default: rc = launch_wgrad<5>(ws, base, B, L, LM, H, W, ks, st); break;
     }
+    if (rc) return rc;
     {
         const size_t n = (size_t)LM * ws.KK;
         hipLaunchKernelGGL(context_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float *)(base + ws.part),
-                           d_conv_w, L, M, ws.KK, ws.ncb, ws.nsl);
+                           d_conv_w, LM, nb, ws.KK, ws.ncb, ws.nsl);
     }
     return (int)hipGetLastError();
 }
