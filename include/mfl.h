@@ -102,14 +102,20 @@ int mfl_local_forward(const float *x, const float *img, const float *cd, const f
  *   dparams: 2 floats, overwritten with {d position_weight, d color_weight}
  *   dcd:     optional [B][H*W][k*k] gradient w.r.t. the colour-distance tensor
  *            (NULL to skip; only allowed with `cd`)
- * With `img` on shapes the diagonal kernels serve (images at least 64 pixels
- * wide, window 3..11; more than 33 labels block by block of output channels) and
- * on large windows over small images (at least 16 x 16 taps on at most 64 K
- * pixels: the reference model's own 50 x 50 window on 64 x 64) the scatter half
- * of dx is summed in 64-bit fixed point (integer atomics): dx is reproducible bit
- * for bit.  The other paths (a `cd` tensor, narrow images, even windows on large
- * images) use float atomics, whose summation order and therefore last bits can
- * differ between runs.
+ * dx is reproducible bit for bit with `img` on two families of shapes:
+ *  - the diagonal kernels' shapes (images at least 64 + k pixels wide, odd window
+ *    3..11, at least k * C * k * k pixels; more than 33 labels block by block of
+ *    output channels): what the window products send to an element of pad(x) is
+ *    stored into one of 2k copies of the gradient planes in which that element
+ *    has a single writer (two, adding atomically onto zero, near the ends of the
+ *    pixel range), and the copies are added in a fixed order.  The workspace
+ *    holds those copies: 2k * B * C * (H + k - 1) * (W + k - 1) floats.
+ *  - large windows over small images (at least 16 x 16 taps on at most 64 K
+ *    pixels: the reference model's own 50 x 50 window on 64 x 64): summed in
+ *    64-bit fixed point with integer atomics.
+ * The other paths (a `cd` tensor, narrow images, even windows on large images)
+ * use float atomics, whose summation order and therefore last bits can differ
+ * between runs.
  */
 int mfl_local_backward(const float *x, const float *img, const float *cd, const float *pos_w, const float *col_w,
                        const float *dy, float *dx, float *dparams, float *dcd, int B, int C, int H, int W, int k,

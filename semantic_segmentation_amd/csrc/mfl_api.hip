@@ -586,6 +586,64 @@ diag_backward_finish_kernel(const float *__restrict__ dy, const float *__restric
     if (threadIdx.x == 0) { partials[2 * blockIdx.x] = sh[0][0]; partials[2 * blockIdx.x + 1] = sh[1][0]; }
 }
 
+// The same for the diagonal kernels' scatter: the scattered term is the sum, in the order of the copies, of the
+// `copies` copies of the padded gradient planes (copy_stride floats apart) the scatter stored into.
+template <int COPIES>
+__global__ void __launch_bounds__(kThreads)
+diag_backward_finish_copies_kernel(const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ P,
+                                   const float *__restrict__ Q, const float *__restrict__ dxc, size_t copy_stride,
+                                   const float *__restrict__ pos_w, const float *__restrict__ col_w, float *__restrict__ dx,
+                                   float *__restrict__ partials, int planes, int H, int W, int Hp, int Wp, int p0)
+{
+    __shared__ float sh[2][kThreads];
+    const float pw = *pos_w, cw = *col_w;
+    const size_t n = (size_t)planes * H * W;
+    float a = 0.f, c = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % W);
+        const size_t rest = i / W;
+        const int yy = (int)(rest % H);
+        const size_t pc = rest / H;
+        const float p = P[i], q = Q[i], g = dy[i], d = g * x[i];
+        const float *src = dxc + (pc * Hp + yy + p0) * Wp + xx + p0;
+        float v[COPIES];
+#pragma unroll
+        for (int s = 0; s < COPIES; ++s) v[s] = __builtin_nontemporal_load(src + (size_t)s * copy_stride);
+        float sc = 0.f;
+#pragma unroll
+        for (int s = 0; s < COPIES; ++s) sc += v[s];
+        dx[i] = fmaf(g, fmaf(pw, p, cw * q), sc);
+        a = fmaf(d, p, a);
+        c = fmaf(d, q, c);
+    }
+    sh[0][threadIdx.x] = a;
+    sh[1][threadIdx.x] = c;
+    __syncthreads();
+    for (int s = kThreads / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = sh[0][0]; partials[2 * blockIdx.x + 1] = sh[1][0]; }
+}
+
+void launch_finish_copies(int k, int blocks, hipStream_t st, const float *dy, const float *x, const float *P, const float *Q,
+                          const float *dxc, size_t copy_stride, const float *pos_w, const float *col_w, float *dx, float *partials,
+                          int planes, int H, int W, int Hp, int Wp, int p0)
+{
+#define MFL_FINISH_CASE(KV)                                                                                                       \
+    case KV:                                                                                                                      \
+        hipLaunchKernelGGL(diag_backward_finish_copies_kernel<2 * KV>, dim3(blocks), dim3(kThreads), 0, st, dy, x, P, Q, dxc,     \
+                           copy_stride, pos_w, col_w, dx, partials, planes, H, W, Hp, Wp, p0);                                    \
+        break;
+    switch (k) {
+        MFL_FINISH_CASE(3) MFL_FINISH_CASE(5) MFL_FINISH_CASE(7) MFL_FINISH_CASE(9) MFL_FINISH_CASE(11)
+    }
+#undef MFL_FINISH_CASE
+}
+
 // dst[CE][CE] = src[C][C] zero-padded: constant row pitch for the fused epilogue's scalar loads
 // dst[c2][c] = src[c][c2], zero-padded to CE2 x CE2 (CE2 even): the layout the fused epilogue reads
 __global__ void pad_compat_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int CE2)
@@ -607,6 +665,8 @@ __global__ void ring_compat_kernel(const float *__restrict__ src, float *__restr
 }
 
 size_t diag_padded_floats(const DiagGeom &g) { return (size_t)g.FS + (size_t)g.B * g.C * g.plane + 3 * (size_t)g.Wp + 64; }
+// floats between the copies of the padded gradient planes the backward scatter stores into
+size_t diag_copy_stride(const DiagGeom &g) { return (diag_padded_floats(g) + 63) / 64 * 64; }
 
 DiagWorkspace diag_carve(int op, const DiagGeom &g)
 {
@@ -621,7 +681,7 @@ DiagWorkspace diag_carve(int op, const DiagGeom &g)
     w.groups = take((size_t)g.k * g.k * 4);
     w.compat = take((size_t)(g.CH * g.NCS + 1) * (g.CH * g.NCS + 1) * 4);
     if (op == MFL_OP_LOCAL_BACKWARD) {
-        w.xp2 = take(diag_padded_floats(g) * 8);          // the padded gradient planes: 64-bit fixed-point sums
+        w.xp2 = take(diag_copy_stride(g) * 2 * g.k * 4);  // 2k copies of the padded gradient planes (one per side and window row)
         w.psum = take((size_t)g.B * g.C * g.L * 4);
         w.qsum = take((size_t)g.B * g.C * g.L * 4);
         w.consts = take(8 * 4);
@@ -631,9 +691,17 @@ DiagWorkspace diag_carve(int op, const DiagGeom &g)
     return w;
 }
 
+// The backward scatter stores each lane's sums into the copy of the gradient planes named by (side, window row): an
+// element's k contributors of one line are k output pixels (C k k - 1) apart, and where that chain crosses the end of
+// the pixel range it continues in the next tap.  With at least k C k k pixels it crosses at most once, so a store
+// target has at most two writers, both lanes with pixels outside the image; those lanes add atomically (two
+// floating-point addends onto zero commute).
+bool diag_scatter_chain_ok(int C, int H, int W, int k) { return (long long)H * W >= (long long)k * C * k * k; }
+
 bool diag_eligible(int op, int B, int C, int H, int W, int k, DiagGeom &g)
 {
     if (op != MFL_OP_LOCAL_FORWARD && op != MFL_OP_MEANFIELD_FORWARD && op != MFL_OP_LOCAL_BACKWARD) return false;
+    if (op == MFL_OP_LOCAL_BACKWARD && !diag_scatter_chain_ok(C, H, W, k)) return false;
     if (op == MFL_OP_MEANFIELD_FORWARD && C > 32) return false;
     return make_diag_geom(g, B, C, H, W, k, kDiagWeightLds, op != MFL_OP_LOCAL_BACKWARD) == 0;
 }
@@ -684,7 +752,7 @@ BlockBackwardWorkspace block_backward_carve(const DiagGeom &g)
     w.f = block_carve(MFL_OP_LOCAL_FORWARD, g);
     size_t off = w.f.total;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    w.dxp = take(diag_padded_floats(g) * 8);
+    w.dxp = take(diag_copy_stride(g) * 2 * g.k * 4);
     w.psum = take((size_t)g.B * g.C * g.L * 4);
     w.qsum = take((size_t)g.B * g.C * g.L * 4);
     w.consts = take(8 * 4);
@@ -983,7 +1051,7 @@ size_t mfl_workspace_bytes(int op, int B, int C, int H, int W, int k, int iters)
     Geom g;
     if (make_geom(g, B, C, H, W, k, 1)) return 0;
     size_t generic = carve(op, g, pick_cc(C)).total;
-    if (diag_block_eligible(B, C, H, W, k, dg)) {
+    if (diag_block_eligible(B, C, H, W, k, dg) && (op != MFL_OP_LOCAL_BACKWARD || diag_scatter_chain_ok(C, H, W, k))) {
         // (more than 33 labels: the diagonal kernels block by block with an image, and in the loop with a label
         // matrix; the generic ones otherwise)
         const size_t blocks = op == MFL_OP_LOCAL_BACKWARD ? block_backward_carve(dg).total : block_carve(op, dg).total;
@@ -1408,7 +1476,8 @@ namespace mfl {
 bool local_backward_split_supported(int B, int C, int H, int W, int k)
 {
     DiagGeom dg;
-    return diag_eligible(MFL_OP_LOCAL_BACKWARD, B, C, H, W, k, dg) || diag_block_eligible(B, C, H, W, k, dg);
+    return diag_eligible(MFL_OP_LOCAL_BACKWARD, B, C, H, W, k, dg) ||
+           (diag_block_eligible(B, C, H, W, k, dg) && diag_scatter_chain_ok(C, H, W, k));
 }
 
 int local_backward_sums(const float *x, const float *img, int B, int C, int H, int W, int k, void *workspace, size_t workspace_bytes,
@@ -1416,7 +1485,7 @@ int local_backward_sums(const float *x, const float *img, int B, int C, int H, i
 {
     DiagGeom dg;
     if (!x || !img) return MFL_ERR_INVALID_ARGUMENT;
-    if (diag_block_eligible(B, C, H, W, k, dg)) {
+    if (diag_block_eligible(B, C, H, W, k, dg) && diag_scatter_chain_ok(C, H, W, k)) {
         // more than 33 labels: block by block of output channels
         const BlockBackwardWorkspace ws = block_backward_carve(dg);
         if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
@@ -1469,18 +1538,15 @@ int local_backward_apply(const float *x, const float *img, const float *pos_w, c
 {
     DiagGeom dg;
     if (!x || !img || !dy || !dx || !dparams) return MFL_ERR_INVALID_ARGUMENT;
-    if (diag_block_eligible(B, C, H, W, k, dg)) {
+    if (diag_block_eligible(B, C, H, W, k, dg) && diag_scatter_chain_ok(C, H, W, k)) {
         const BlockBackwardWorkspace ws = block_backward_carve(dg);
         if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
         char *base = (char *)workspace;
         hipStream_t st = (hipStream_t)stream;
-        float *consts = (float *)(base + ws.consts), *P = (float *)(base + ws.psum), *Q = (float *)(base + ws.qsum);
-        float *dxp = (float *)(base + ws.dxp), *partials = (float *)(base + ws.partials);   // (dxp: 64-bit elements)
-        const size_t n = (size_t)B * C * dg.L;
-        hipLaunchKernelGGL(diag_backward_absmax_kernel, dim3(grid_for(n) < 1024 ? grid_for(n) : 1024), dim3(kThreads), 0, st, dy, x, n, img,
-                           (size_t)B * 3 * dg.L, consts);
-        hipLaunchKernelGGL(diag_backward_scale_kernel, dim3(1), dim3(64), 0, st, pos_w, col_w, k, consts);
-        MFL_CHECK_HIP(hipMemsetAsync(dxp, 0, diag_padded_floats(dg) * 8, st));
+        float *P = (float *)(base + ws.psum), *Q = (float *)(base + ws.qsum);
+        float *dxp = (float *)(base + ws.dxp), *partials = (float *)(base + ws.partials);
+        const size_t n = (size_t)B * C * dg.L, cs = diag_copy_stride(dg);
+        MFL_CHECK_HIP(hipMemsetAsync(dxp, 0, cs * 2 * k * 4, st));
         DiagArgs da{};
         diag_lds(dg, da);
         da.xp = (const float *)(base + ws.f.xp);
@@ -1489,7 +1555,7 @@ int local_backward_apply(const float *x, const float *img, const float *pos_w, c
         da.pos_w = pos_w; da.col_w = col_w; da.y = nullptr;
         da.unary = dy;
         da.qp_out = dxp;
-        da.aw = consts + 4;                       // the scatter's fixed-point scale
+        da.copy_stride = cs;
         for (int blk = 0; blk < ws.f.nblk; ++blk) {
             da.g = block_geom(dg, blk);
             da.table = (const uint32_t *)(base + ws.f.table + blk * ws.f.table_stride);
@@ -1497,8 +1563,7 @@ int local_backward_apply(const float *x, const float *img, const float *pos_w, c
             if (rc) return rc;
         }
         const int blocks = grid_for(n) < kDiagBackwardBlocks ? grid_for(n) : kDiagBackwardBlocks;
-        hipLaunchKernelGGL(diag_backward_finish_kernel, dim3(blocks), dim3(kThreads), 0, st, dy, x, P, Q, (const long long *)dxp + dg.FS, consts,
-                           pos_w, col_w, dx, partials, B * C, H, W, dg.Hp, dg.Wp, dg.p0);
+        launch_finish_copies(k, blocks, st, dy, x, P, Q, dxp + dg.FS, cs, pos_w, col_w, dx, partials, B * C, H, W, dg.Hp, dg.Wp, dg.p0);
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kThreads), 0, st, partials, blocks, dparams);
         return (int)hipGetLastError();
     }
@@ -1507,13 +1572,10 @@ int local_backward_apply(const float *x, const float *img, const float *pos_w, c
     if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
     char *base = (char *)workspace;
     hipStream_t st = (hipStream_t)stream;
-    float *consts = (float *)(base + ws.consts), *P = (float *)(base + ws.psum), *Q = (float *)(base + ws.qsum);
-    float *dxp = (float *)(base + ws.xp2), *partials = (float *)(base + ws.partials);   // (dxp: 64-bit elements)
-    const size_t n = (size_t)B * C * dg.L;
-    hipLaunchKernelGGL(diag_backward_absmax_kernel, dim3(grid_for(n) < 1024 ? grid_for(n) : 1024), dim3(kThreads), 0, st, dy, x, n, img,
-                       (size_t)B * 3 * dg.L, consts);
-    hipLaunchKernelGGL(diag_backward_scale_kernel, dim3(1), dim3(64), 0, st, pos_w, col_w, k, consts);
-    MFL_CHECK_HIP(hipMemsetAsync(dxp, 0, diag_padded_floats(dg) * 8, st));
+    float *P = (float *)(base + ws.psum), *Q = (float *)(base + ws.qsum);
+    float *dxp = (float *)(base + ws.xp2), *partials = (float *)(base + ws.partials);
+    const size_t n = (size_t)B * C * dg.L, cs = diag_copy_stride(dg);
+    MFL_CHECK_HIP(hipMemsetAsync(dxp, 0, cs * 2 * k * 4, st));
     DiagArgs da{};
     da.g = dg;
     diag_lds(dg, da);
@@ -1524,12 +1586,11 @@ int local_backward_apply(const float *x, const float *img, const float *pos_w, c
     da.pos_w = pos_w; da.col_w = col_w; da.y = nullptr;
     da.unary = dy;
     da.qp_out = dxp;
-    da.aw = consts + 4;                       // the scatter's fixed-point scale
+    da.copy_stride = cs;
     const int rc = dispatch_diag(da, 3, st);
     if (rc) return rc;
     const int blocks = grid_for(n) < kDiagBackwardBlocks ? grid_for(n) : kDiagBackwardBlocks;
-    hipLaunchKernelGGL(diag_backward_finish_kernel, dim3(blocks), dim3(kThreads), 0, st, dy, x, P, Q, (const long long *)dxp + dg.FS, consts,
-                       pos_w, col_w, dx, partials, B * C, H, W, dg.Hp, dg.Wp, dg.p0);
+    launch_finish_copies(k, blocks, st, dy, x, P, Q, dxp + dg.FS, cs, pos_w, col_w, dx, partials, B * C, H, W, dg.Hp, dg.Wp, dg.p0);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kThreads), 0, st, partials, blocks, dparams);
     return (int)hipGetLastError();
 }

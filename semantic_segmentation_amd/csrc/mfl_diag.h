@@ -119,6 +119,11 @@ inline int diag_block_width(int C)
 //                          step | (TA + 64) << 8 | (TB + 64) << 16
 //   [xw base, ...)       16-bit pairs: xA | (xB != xA) << 15   (lane-0 source columns, for the steps
 //                        past the slots)
+//   [kyw base, ...)      one byte per step: ky' of A | ky' of B << 4, the window row of the line (c', ky') the
+//                        side's element belongs to.  An element of pad(x) is shared by k lines (one per window
+//                        row that reaches it), and in each line by the side A of one lane and the side B of
+//                        another: (side, ky') names which of its 2k contributors a lane is, which lets the
+//                        backward store what it sends to an element instead of adding it atomically.
 // A flagged side is described by a threshold T (diag_side): with p = lane - T, pixel n of the lane
 // reads the table's element ("shared") if p < n and the element gap floats further ("extra") if
 // p >= n.  Where the run wraps to the next image row at lane T (1 <= T <= 63) the table holds the
@@ -127,7 +132,8 @@ inline int diag_block_width(int C)
 constexpr int kDiagSlots = 3;
 MFL_HD int diag_slot_base(int CH) { return 2 * CH + 1; }
 MFL_HD int diag_xw_base(int CH) { return 2 * CH + 1 + kDiagSlots; }
-MFL_HD int diag_recw(int CH) { return ((diag_xw_base(CH) + (CH + 1) / 2 + 3) / 4) * 4; }
+MFL_HD int diag_kyw_base(int CH) { return diag_xw_base(CH) + (CH + 1) / 2; }
+MFL_HD int diag_recw(int CH) { return ((diag_kyw_base(CH) + (CH + 3) / 4 + 3) / 4) * 4; }
 
 // A last b-block with at most this many live lanes is not run by the diagonal kernels (unless the
 // caller asks for all blocks: the backward does, its tail pixels would scatter one 4-byte atomic per
@@ -198,6 +204,7 @@ MFL_HD size_t diag_record_index(const DiagGeom &g, int beta, int gamma, int t, i
 //   flagged      the 64-lane run meets an image-row start: the per-lane corrected path is needed.
 struct DiagStep {
     int offA, offB, xA, xB;
+    int kyA, kyB;             // window row of the line A / B belongs to
     bool flagged;
 };
 
@@ -214,6 +221,7 @@ MFL_HD DiagStep diag_step(const DiagGeom &g, int beta, int gamma, int t, int c)
     st.xA = (int)(uA - (long long)yA * g.W);
     const int cA = rho / g.k, kyA = rho - cA * g.k;
     st.offA = g.FS + cA * g.plane + (yA + kyA) * g.Wp + st.xA + s;
+    st.kyA = kyA;
     // B: the next line, possibly of the next source pixel
     long long uB = uA;
     int rhoB = rho + 1;
@@ -222,6 +230,7 @@ MFL_HD DiagStep diag_step(const DiagGeom &g, int beta, int gamma, int t, int c)
     st.xB = (int)(uB - (long long)yB * g.W);
     const int cB = rhoB / g.k, kyB = rhoB - cB * g.k;
     st.offB = g.FS + cB * g.plane + (yB + kyB) * g.Wp + st.xB + s - g.k;
+    st.kyB = kyB;
     const bool okA = st.xA >= g.k - 1 && st.xA + 63 <= g.W - 1;
     const bool okB = st.xB >= g.k - 1 && st.xB + 63 <= g.W - 1;
     st.flagged = !(okA && okB);
@@ -271,7 +280,7 @@ MFL_HD void diag_fill_record(const DiagGeom &g, int beta, int gamma, int t, int 
 {
     uint32_t flags = 0;
     int nslots = 0, nflagged = 0;
-    const int sb = diag_slot_base(g.CH), xb = diag_xw_base(g.CH);
+    const int sb = diag_slot_base(g.CH), xb = diag_xw_base(g.CH), kb = diag_kyw_base(g.CH);
     for (int i = 0; i < g.RECW; ++i) rec[i] = 0;
     for (int i = 0; i < g.CH; ++i) {
         int c = ci * g.CH + i;
@@ -285,6 +294,7 @@ MFL_HD void diag_fill_record(const DiagGeom &g, int beta, int gamma, int t, int 
         rec[g.CH + i] = (uint32_t)oB * 4u;
         const uint32_t x16 = (uint32_t)st.xA | ((st.xB != st.xA) ? 0x8000u : 0u);
         rec[xb + i / 2] |= x16 << (16 * (i & 1));
+        rec[kb + i / 4] |= ((uint32_t)st.kyA | ((uint32_t)st.kyB << 4)) << (8 * (i & 3));
         if (st.flagged && !dummy) {
             flags |= 1u << i;
             ++nflagged;

@@ -15,7 +15,9 @@
 // consecutive lanes = consecutive pixels) for the fused normalise step or the plain product.
 // The backward reuses the machinery transposed: D = dy * x enters through LDS into the accumulator
 // registers, and per (channel, tap) a lane sums what its k pixels send to the shared element and
-// adds it to the gradient planes with one 64-bit fixed-point integer atomic (tap_scatter).
+// stores the sum into the copy of the gradient planes that belongs to (side, window row of the element's
+// line): every element has one writer per copy, so no atomic is needed and the 2k copies are added in a
+// fixed order afterwards (tap_scatter).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -237,8 +239,9 @@ __device__ __forceinline__ uint32_t rec_word(uint32_t recv, int j)
 template <int CH, int KS, int NGW, int NCS, bool BWD>
 struct Loop {
     using Cfg = DiagCfg<CH, KS, NGW, NCS>;
-    unsigned long long *scatter_out;        // BWD: FS elements before the image's zeroed padded planes of 64-bit fixed-point sums
-    float fscale;                           // BWD: the fixed-point scale (a power of two)
+    float *scatter_out;                     // BWD: FS floats before the image's padded planes in copy 0 of the gradient planes (zeroed)
+    size_t copy_stride;                     // BWD: floats between consecutive copies
+    bool edge;                              // BWD (wave-uniform): a lane of the wave is an edge lane
     int C, ci;                              // BWD: channels of the launch (a block of a larger label set, or all), this wave's channel split
     DiagState<CH, KS, NGW, NCS> &st;
     __amdgpu_buffer_rsrc_t rsrc;
@@ -402,31 +405,55 @@ struct Loop {
     }
 
     // Backward of one tap (the transpose of tap()): st.acc holds D = dy * x of the lane's pixels; what
-    // the k pixels of a side send to their shared element is summed and added to the gradient planes
-    // with one 64-bit fixed-point integer atomic per lane (fixed_point_add: the sums do not depend on the order).  A flagged side splits the sum
-    // between the shared and the extra element by the same rule the gather reads them.
+    // the k pixels of a side send to their shared element is summed and stored.  An element of pad(x) belongs to
+    // k lines (c', ky'), and within a line to the side A of one lane-step and the side B of another (mfl_diag.h):
+    // (side, ky') selects one of 2k copies of the gradient planes in which this lane-step is the element's only
+    // writer, so a plain store serves and the result does not depend on any order.  A flagged side splits the sum
+    // between the shared and the extra element by the same rule the gather reads them; both are elements of the
+    // same line and side.  (An earlier version added into one set of planes with 64-bit fixed-point atomics: 3.7 ms
+    // at 21 labels, 512 x 512, 7 x 7, 8 images, bound by the rate of atomic operations.)
 #ifdef MFL_ABL_NO_ATOMIC
-    // timing experiment: the sums are formed, the atomics replaced by a store no launch performs
-    __device__ __forceinline__ void scatter_add(unsigned long long *p, float v) const { if (v == 1234.5678f) *p = 1; }
+    // timing experiment: the sums are formed, the stores replaced by one no launch performs
+    template <bool EDGE>
+    __device__ __forceinline__ void scatter_store(float *p, float v) const { if (v == 1234.5678f) *p = 1.f; }
 #else
-    // (lanes whose pixels are all outside the image hold D = 0: they send nothing)
-    __device__ __forceinline__ void scatter_add(unsigned long long *p, float v) const
+    // (lanes whose pixels are all outside the image hold D = 0: they store nothing, the copies were zeroed.  Where a
+    // chain of an element's contributors leaves the pixel range, it continues in the neighbouring tap, whose alignment
+    // class may differ: then two lanes send to the same side's copy.  Both are edge lanes, which add atomically; two
+    // addends onto zero give the same sum in either order)
+    // (a wave with an edge lane adds atomically in all its lanes - an atomic costs the same for six lanes as for 64,
+    // and a store beside it in the other lanes costs more than it saves: 4.7 against 2.2 ms -; the two forms are
+    // separate bodies chosen by a wave-uniform branch per tap.  The first and the last b-block are such waves.)
+    template <bool EDGE>
+    __device__ __forceinline__ void scatter_store(float *p, float v) const
     {
-        if (v != 0.f) fixed_point_add(p, v, fscale);
+        if (v != 0.f) {
+            if constexpr (EDGE) unsafeAtomicAdd(p, v);
+            else *p = v;
+        }
     }
 #endif
     template <int SA>
     __device__ __forceinline__ void tap_scatter(const float (&w)[KS])
     {
+        if (edge) tap_scatter_body<SA, true>(w);
+        else tap_scatter_body<SA, false>(w);
+    }
+    template <int SA, bool EDGE>
+    __device__ __forceinline__ void tap_scatter_body(const float (&w)[KS])
+    {
         const uint32_t rec_new = request_record();
         const uint32_t hdr = rec_word(rec_use, 2 * CH);
-        unsigned long long *base = scatter_out + lane;
+        float *base = scatter_out + lane;
         constexpr int NA = KS - SA;
         auto threshold = [&](int x0) { return x0 + 63 > W - 1 ? W - x0 : (x0 < KS - 1 ? -x0 : 64); };
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             if (ci * CH + i < C) {
                 const uint32_t oA = rec_word(rec_use, i) >> 2, oB = rec_word(rec_use, CH + i) >> 2;
+                const uint32_t kyw = rec_word(rec_use, diag_kyw_base(CH) + (i >> 2)) >> (8 * (i & 3));
+                float *dstA = base + (size_t)(kyw & 15u) * copy_stride + oA;
+                float *dstB = base + (size_t)(KS + ((kyw >> 4) & 15u)) * copy_stride + oB;
                 if ((hdr >> i) & 1) {
                     const uint32_t x16 = (rec_word(rec_use, diag_xw_base(CH) + (i >> 1)) >> (16 * (i & 1))) & 0xffffu;
                     const int xA = x16 & 0x7fff;
@@ -439,11 +466,11 @@ struct Loop {
                         if (n < NA) { if (pA >= n) eA += t; else sA += t; }
                         else { if (pB >= n) eB += t; else sB += t; }
                     }
-                    scatter_add(base + oA, sA);
-                    scatter_add(base + oA + (gap4 >> 2), eA);
+                    scatter_store<EDGE>(dstA, sA);
+                    scatter_store<EDGE>(dstA + (gap4 >> 2), eA);
                     if constexpr (SA > 0) {
-                        scatter_add(base + oB, sB);
-                        scatter_add(base + oB + (gap4 >> 2), eB);
+                        scatter_store<EDGE>(dstB, sB);
+                        scatter_store<EDGE>(dstB + (gap4 >> 2), eB);
                     }
                 } else {
                     float dA = 0.f, dB = 0.f;
@@ -452,8 +479,8 @@ struct Loop {
                         if (n < NA) dA = fmaf(w[n], st.acc[i][n], dA);
                         else dB = fmaf(w[n], st.acc[i][n], dB);
                     }
-                    scatter_add(base + oA, dA);
-                    if constexpr (SA > 0) scatter_add(base + oB, dB);
+                    scatter_store<EDGE>(dstA, dA);
+                    if constexpr (SA > 0) scatter_store<EDGE>(dstB, dB);
                 }
             }
         }
@@ -564,15 +591,16 @@ struct Loop {
 };
 
 // MODE 0: fused mean-field update   MODE 1: y = x * window sums   MODE 2: y = window sums
-// MODE 3: backward scatter: gradient planes (qp_out, zeroed by the caller) += transpose of the window
-//         sums applied to D = dy * x (dy passed as `unary`)
+// MODE 3: backward scatter: the 2k copies of the gradient planes (qp_out, zeroed by the caller, copy_stride floats
+//         apart) receive the transpose of the window sums applied to
+//         D = dy * x (dy passed as `unary`)
 template <int CH, int KS, int NGW, int NCS, int MODE>
 __global__ void __launch_bounds__(64 * NGW * NCS)
 diag_kernel(DiagGeom g, int epi_rows, int tail_per_group, const float *__restrict__ xp, const F4 *__restrict__ ip4,
             const uint32_t *__restrict__ table, const uint32_t *__restrict__ groups, const float *__restrict__ pos_w,
             const float *__restrict__ col_w, const float *__restrict__ unary, const float *__restrict__ aw,
             const float *__restrict__ ab, const float *__restrict__ compat, const float *__restrict__ compat_plain,
-            float *__restrict__ logq, float *__restrict__ qp_out, float *__restrict__ y_out,
+            float *__restrict__ logq, float *__restrict__ qp_out, float *__restrict__ y_out, size_t copy_stride,
             unsigned long long *__restrict__ dbg)
 {
     MFL_STAMP(0);
@@ -688,7 +716,17 @@ diag_kernel(DiagGeom g, int epi_rows, int tail_per_group, const float *__restric
             __syncthreads();
         }
     }
-    Loop<CH, KS, NGW, NCS, MODE == 3> loop{reinterpret_cast<unsigned long long *>(qp_out) + img_off, MODE == 3 ? aw[0] : 0.f, g.Cv, ci, st, rsrc,
+    // pixels (a0 + n, b - n) of this lane: the first has the largest index, the last the smallest.  The k contributors
+    // of an element in one line are k pixels (CK - 1) apart, this lane's among them: where that chain may leave the
+    // pixel range, the lane counts as an edge lane (Loop::scatter_store).
+    bool edge = false;
+    if constexpr (MODE == 3) {
+        const long long l_first = (long long)gamma * KS + ((long long)64 * beta + lane) * CK;
+        const long long l_last = l_first + (KS - 1) - (long long)(KS - 1) * CK;
+        const long long span = (long long)(KS - 1) * (CK - 1);
+        edge = __builtin_amdgcn_ballot_w64(l_last < span || l_first >= L - span) != 0;
+    }
+    Loop<CH, KS, NGW, NCS, MODE == 3> loop{qp_out + img_off, copy_stride, edge, g.Cv, ci, st, rsrc,
                                            table + diag_record_index(g, beta, live ? gamma : 0, 0, ci), groups, irsrc, lds,
                                            pw, cw, g.ngroups, g.TB, g.NCS * g.RECW, g.RECW, g.p0, Wp, W, g.gap * 4, gi,
                                            lane, live, dbg};
@@ -906,7 +944,7 @@ int launch_cfg(const DiagArgs &a, int mode, hipStream_t st)
         const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), lds, st, a.g, a.epi_rows, tail_per_group, a.xp, a.ip4, a.table, a.groups,
-                           a.pos_w, a.col_w, a.unary, a.aw, a.ab, a.compat, a.compat_plain, a.logq, a.qp_out, a.y, a.dbg);
+                           a.pos_w, a.col_w, a.unary, a.aw, a.ab, a.compat, a.compat_plain, a.logq, a.qp_out, a.y, a.copy_stride, a.dbg);
         return 0;
     };
     int rc;

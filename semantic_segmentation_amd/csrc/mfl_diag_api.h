@@ -23,6 +23,7 @@ struct DiagArgs {
     const float *compat_plain;               // mode 0: the caller's C x C matrix (tail pixels), or NULL
     float *logq, *qp_out;                    // mode 0: qp_out has the layout of xp
     float *y;                                // mode 1
+    size_t copy_stride;                      // mode 3: qp_out holds 2k copies of the gradient planes, this many floats apart
     unsigned long long *dbg;                 // cycle stamps of diagnostic builds (-DMFL_STAMPS), else NULL
 };
 

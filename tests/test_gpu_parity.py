@@ -373,8 +373,9 @@ def test_config4_full_image_meanfield_step_vs_oracle(S, oracle):
 
 def test_backward_full_512_image_vs_oracle_and_bitwise_reproducible(S, oracle):
     """21 labels, 512x512, 7x7, batch 4 (one GPU's share of the training configuration): image 2 of the batch
-    against the C oracle, and the whole dx bit for bit equal between two runs (the scatter is summed in
-    64-bit fixed point, so the order of the adds does not matter)."""
+    against the C oracle, and the whole dx bit for bit equal between two runs (every element of the scatter's 2k copies
+    of the gradient planes has one writer, or two that add onto zero; the copies are summed in a fixed order).  The
+    second run finds the first run's contents in the workspace."""
     shape = (4, 21, 512, 512, 7)
     x, img, dy = make_inputs(shape, 21)
     pw, cw = scalar(-0.004), scalar(-0.003)
@@ -391,8 +392,8 @@ def test_backward_full_512_image_vs_oracle_and_bitwise_reproducible(S, oracle):
 
 
 def test_backward_fixed_point_scale_follows_the_data(S, oracle):
-    """The fixed-point scale of the scatter is derived from max|dy*x| and max|img|: gradients 1e6 times larger or
-    smaller keep the same relative accuracy."""
+    """Gradients 1e6 times larger or smaller keep the same relative accuracy (the diagonal kernels' scatter sums plain
+    fp32; the tap-split backward of large windows derives a fixed-point scale from max|dy*x| and max|img|)."""
     shape = (1, 8, 70, 96, 5)
     x, img, dy = make_inputs(shape, 22)
     for f in (1e-6, 1.0, 1e6):
