@@ -1,21 +1,22 @@
 #!/usr/bin/env python3
-"""Copies the summaries of gpurun_out/r02 (tools/profile_all.sh) into profiles/: kernel_stats csv per trace,
+"""Copies the summaries of gpurun_out/<round> (tools/profile_all.sh; round tag from $ROUND, default r03) into profiles/: kernel_stats csv per trace,
 one text file of mean counter values per dispatch for the kernels of interest per counter run, and
 profiles/traffic.json (memory-side bytes per launch of the fused step kernels)."""
 import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r02")
+ROUND = os.environ.get("ROUND", "r03")
+SRC = os.path.join(ROOT, "gpurun_out", ROUND)
 DST = os.path.join(ROOT, "profiles")
 
-for tag in ("c4", "c2", "c5", "ops", "k50"):
+for tag in ("c4", "c2", "c5", "ops", "k50", "ctx", "train"):
     for f in glob.glob(os.path.join(SRC, f"trace_{tag}", "**", "*kernel_stats.csv"), recursive=True):
-        shutil.copy(f, os.path.join(DST, f"r02_{tag}_kernel_stats.csv"))
+        shutil.copy(f, os.path.join(DST, f"{ROUND}_{tag}_kernel_stats.csv"))
     log = os.path.join(SRC, f"trace_{tag}.log")
     if os.path.exists(log):
-        lines = [l for l in open(log) if l.startswith("{") or "ms" in l and "B" in l and "k" in l and not l.startswith("W2")]
-        with open(os.path.join(DST, f"r02_{tag}_under_rocprof.txt"), "w") as out:
+        lines = [l for l in open(log) if l.startswith("{") or " ms" in l and not l.startswith(("W2", "E2", "I2"))]
+        with open(os.path.join(DST, f"{ROUND}_{tag}_under_rocprof.txt"), "w") as out:
             out.writelines(l for l in lines if "amdgpu.ids" not in l)
 
 
@@ -32,11 +33,12 @@ def counters(tag, patterns):
 
 
 KERNELS = {"c4": ["ring_kernel", "weights_kernel"], "c2": ["diag_kernel"], "c5": ["diag_kernel", "label_step_kernel"],
-           "ops": ["diag_kernel", "diag_backward_finish", "diag_backward_absmax"]}
+           "ops": ["diag_kernel", "diag_backward_finish"],
+           "ctx": ["label_context_kernel", "context_wgrad_kernel", "context_pre_kernel"]}
 traffic = {}
 for tag, pats in KERNELS.items():
     acc = counters(tag, pats)
-    with open(os.path.join(DST, f"r02_pmc_{tag}.txt"), "w") as out:
+    with open(os.path.join(DST, f"{ROUND}_pmc_{tag}.txt"), "w") as out:
         out.write(f"rocprofv3 --pmc passes of tools/profile_all.sh ({tag}); mean counter value per dispatch\n")
         for p in pats:
             out.write(f"\n== kernels matching '{p}'\n")
@@ -50,9 +52,9 @@ for tag, pats in KERNELS.items():
         traffic[tag] = {"kernel": step, "fetch_size_kb_per_launch": fetch, "write_size_kb_per_launch": write,
                         "fetch_correction": 2.0, "traffic_bytes_per_launch": int((2 * fetch + write) * 1024),
                         "pixels_per_launch": {"c4": 16 * 1024 * 2048, "c2": 8 * 512 * 512}[tag],
-                        "sources": [f"profiles/r02_pmc_{tag}.txt", "profiles/r02_pmc_fetch_calibration.txt"]}
+                        "sources": [f"profiles/{ROUND}_pmc_{tag}.txt", f"profiles/{ROUND}_pmc_fetch_calibration.txt"]}
 for path in glob.glob(os.path.join(SRC, "pmc_calib", "**", "*counter_collection.csv"), recursive=True):
-    with open(os.path.join(DST, "r02_pmc_fetch_calibration.txt"), "w") as out:
+    with open(os.path.join(DST, f"{ROUND}_pmc_fetch_calibration.txt"), "w") as out:
         out.write("tools/exp/exp_calib_fetch (1 GiB streamed once, one dword per lane and load) under rocprofv3 --pmc FETCH_SIZE\n")
         for r in csv.DictReader(open(path)):
             out.write(f"{r['Kernel_Name'][:60]}  {r['Counter_Name']} = {r['Counter_Value']} KB\n")
