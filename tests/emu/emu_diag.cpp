@@ -153,3 +153,71 @@ extern "C" int emu_diag_geom_status(int B, int C, int H, int W, int k)
     DiagGeom g;
     return make_diag_geom(g, B, C, H, W, k, 96 * 1024);
 }
+
+// The backward scatter's store targets (diag_kernel MODE 3, mfl_diag.hip), replayed from the table records: per
+// (b-block, group, tap, channel, lane) the copy index (side, window row of the record's ky byte) and the float index
+// of the shared and of the extra element that receive a sum.  Counts the targets with more than one writer; a lane is
+// an edge lane by the kernel's rule (within (k-1)(CK-1) pixels of either end of the pixel range).
+// out[0] = targets with two or more writers, out[1] = of those, targets with a writer that is no edge lane,
+// out[2] = largest number of writers of one target, out[3] = targets written.
+extern "C" int emu_diag_scatter_targets(int C, int H, int W, int k, long long *out)
+{
+    DiagGeom g;
+    int rc = make_diag_geom(g, 1, C, H, W, k, 96 * 1024, false);
+    if (rc) return rc;
+    struct Writers { int n; bool non_edge; };
+    std::vector<std::vector<Writers>> seen(2 * k, std::vector<Writers>((size_t)g.FS + (size_t)C * g.plane + 3 * g.Wp + 64, Writers{0, false}));
+    std::vector<uint32_t> rec(g.RECW);
+    const long long span = (long long)(k - 1) * (g.CK - 1);
+    auto threshold = [&](int x0) { return x0 + 63 > W - 1 ? W - x0 : (x0 < k - 1 ? -x0 : 64); };
+    for (int beta = 0; beta < g.NBB; ++beta)
+        for (int gamma = 0; gamma < g.NG; ++gamma)
+            for (int t = 0; t < g.K; ++t) {
+                const int NA = k - diag_align(g, t % k);
+                for (int ci = 0; ci < g.NCS; ++ci) {
+                    diag_fill_record(g, beta, gamma, t, ci, rec.data());
+                    const uint32_t hdr = rec[2 * g.CH];
+                    for (int i = 0; i < g.CH; ++i) {
+                        if (ci * g.CH + i >= C) continue;
+                        const uint32_t oA = rec[i] >> 2, oB = rec[g.CH + i] >> 2;
+                        const uint32_t kyw = rec[diag_kyw_base(g.CH) + (i >> 2)] >> (8 * (i & 3));
+                        const int copyA = kyw & 15, copyB = k + ((kyw >> 4) & 15);
+                        const bool flagged = (hdr >> i) & 1;
+                        const uint32_t x16 = (rec[diag_xw_base(g.CH) + (i >> 1)] >> (16 * (i & 1))) & 0xffffu;
+                        const int xA = x16 & 0x7fff;
+                        const int xB = (x16 & 0x8000) ? (xA + 1 == W ? 0 : xA + 1) : xA;
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const long long l_first = (long long)gamma * k + ((long long)64 * beta + lane) * g.CK;
+                            const long long l_last = l_first + (k - 1) - (long long)(k - 1) * g.CK;
+                            const bool edge = l_last < span || l_first >= g.L - span;
+                            const int pA = lane - threshold(xA), pB = lane - threshold(xB);
+                            bool w[4] = {false, false, false, false};      // shared A, extra A, shared B, extra B
+                            for (int n = 0; n < k; ++n) {
+                                const long long l = l_first + n - (long long)n * g.CK;
+                                if (l < 0 || l >= g.L) continue;          // D = 0: nothing is sent
+                                if (n < NA) w[(flagged && pA >= n) ? 1 : 0] = true;
+                                else w[(flagged && pB >= n) ? 3 : 2] = true;
+                            }
+                            auto put = [&](int copy, size_t idx) {
+                                Writers &s = seen[copy][idx];
+                                s.n += 1;
+                                s.non_edge = s.non_edge || !edge;
+                            };
+                            if (w[0]) put(copyA, (size_t)oA + lane);
+                            if (w[1]) put(copyA, (size_t)oA + lane + g.gap);
+                            if (w[2]) put(copyB, (size_t)oB + lane);
+                            if (w[3]) put(copyB, (size_t)oB + lane + g.gap);
+                        }
+                    }
+                }
+            }
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (auto &copy : seen)
+        for (auto &s : copy) {
+            if (s.n == 0) continue;
+            out[3] += 1;
+            if (s.n > out[2]) out[2] = s.n;
+            if (s.n > 1) { out[0] += 1; if (s.non_edge) out[1] += 1; }
+        }
+    return 0;
+}

@@ -49,3 +49,20 @@ def test_unsupported_shapes_are_rejected(emu_diag):
         rc = emu_diag.emu_diag_local_forward(x.ctypes.data_as(F), img.ctypes.data_as(F), ctypes.c_float(0.3),
                                              ctypes.c_float(-0.7), x.ctypes.data_as(F), cnt.ctypes.data_as(I), 1, 3, 8, 60, k)
         assert rc == -1
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 128, 3), (21, 96, 112, 7), (23, 70, 90, 5), (9, 50, 75, 3), (12, 100, 120, 9),
+                                   (19, 128, 160, 7), (6, 200, 100, 7), (8, 130, 96, 11)])
+def test_backward_scatter_targets_have_one_writer_or_two_edge_lanes(shape, emu_diag):
+    """The diagonal backward stores a lane's sum into the copy of the gradient planes named by (side, window row of the
+    record): replayed from the table records for every (b-block, group, tap, channel, lane), a target has one writer, or
+    two that are both edge lanes by the kernel's rule (those add atomically, two addends onto zero), on shapes with at
+    least k * C * k * k pixels (the entry point's condition for this path)."""
+    C, H, W, k = shape
+    assert H * W >= k * C * k * k
+    out = (ctypes.c_longlong * 4)()
+    assert emu_diag.emu_diag_scatter_targets(C, H, W, k, out) == 0
+    multi, multi_non_edge, most, written = out[0], out[1], out[2], out[3]
+    assert written > 0
+    assert most <= 2, f"{most} writers on one target"
+    assert multi_non_edge == 0, f"{multi_non_edge} of {multi} shared targets have a writer that stores instead of adding"
