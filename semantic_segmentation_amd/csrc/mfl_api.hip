@@ -740,7 +740,7 @@ BlockWorkspace block_carve(int op, const DiagGeom &g)
 }
 
 // The local backward block by block of output channels (more than 33 labels): the forward's padded planes, image and
-// per-block tables, plus what the diagonal backward adds (fixed-point gradient planes, plain window sums, constants).
+// per-block tables, plus what the diagonal backward adds (the 2k copies of the gradient planes, plain window sums, constants).
 struct BlockBackwardWorkspace {
     BlockWorkspace f;
     size_t dxp, psum, qsum, consts, partials, total;

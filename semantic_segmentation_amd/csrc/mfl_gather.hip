@@ -571,7 +571,7 @@ int launch_step(const GatherArgs &a, const StepArgs &s, hipStream_t st)
 
 // Pixels per thread the image-weight, LDS-table variants are built for at this width
 // (accumulator tile CC*M kept within the register budget).
-constexpr int kMaxM = (MFL_CC * 4 <= 96) ? 4 : 2;
+[[maybe_unused]] constexpr int kMaxM = (MFL_CC * 4 <= 96) ? 4 : 2;
 
 }  // namespace
 

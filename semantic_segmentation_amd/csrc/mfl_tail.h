@@ -36,6 +36,8 @@ __device__ __forceinline__ void diag_tail_block(const DiagGeom &g, float *tail_l
                                                 float *__restrict__ logq, float *__restrict__ qp_out,
                                                 float *__restrict__ y_out)
 {
+    // (the backward scatter, MODE 3, runs every b-block as regular workgroups: its launches have no tail workgroups)
+    if constexpr (MODE == 3) return;
     const int chunks = (per_group + kTailPix - 1) / kTailPix;
     const long long nwaves = (long long)g.B * g.NG * chunks;
     const int C = g.C, K = g.K, k = g.k, W = g.W, Wp = g.Wp, L = g.L, CK = g.CK;
@@ -99,27 +101,18 @@ __device__ __forceinline__ void diag_tail_block(const DiagGeom &g, float *tail_l
         // what depends on (pixel, channel) only is requested before the taps
         qv[j] = in_b[(size_t)cc * g.plane + cpos];
         uv[j] = 0.f; av[j] = 1.f; bv[j] = 0.f;
-        if constexpr (MODE == 0 || MODE == 3) uv[j] = unary[((size_t)img * C + cc) * L + l];
+        if constexpr (MODE == 0) uv[j] = unary[((size_t)img * C + cc) * L + l];
         if constexpr (MODE == 0) {
             if (aw) { av[j] = aw[(size_t)cc * L + l]; bv[j] = ab[(size_t)cc * L + l]; }
         }
-        if constexpr (MODE == 3) qv[j] = (valid && c < C) ? qv[j] * uv[j] : 0.f;   // D = dy * x
     }
-    // MODE 3: qp_out holds 64-bit fixed-point sums (same element indices), aw[0] the scale
-    unsigned long long *grad_b = reinterpret_cast<unsigned long long *>(qp_out) + img_off + g.FS;
-    const float fscale = MODE == 3 ? aw[0] : 0.f;
 #pragma unroll 4
     for (int t = 0; t < K; ++t) {
         const float wv = wt[p * K + t];
 #pragma unroll
         for (int j = 0; j < kTailChan; ++j) {
             const unsigned ys = lp[j] / (unsigned)W, xs = lp[j] - ys * (unsigned)W;
-#ifdef MFL_ABL_NO_TAIL_ATOMIC
-            if constexpr (MODE == 3) acc[j] += wv * qv[j] * (float)(tab[rr[j]] + ys * Wp + xs);
-#else
-            if constexpr (MODE == 3) { if (wv * qv[j] != 0.f) fixed_point_add(grad_b + tab[rr[j]] + ys * Wp + xs, wv * qv[j], fscale); }
-#endif
-            else acc[j] = fmaf(wv, in_b[tab[rr[j]] + ys * Wp + xs], acc[j]);
+            acc[j] = fmaf(wv, in_b[tab[rr[j]] + ys * Wp + xs], acc[j]);
             lp[j] += qL;
             rr[j] += rL;
             if (rr[j] >= (unsigned)CK) { rr[j] -= CK; ++lp[j]; }
