@@ -253,6 +253,8 @@ struct Loop {
     int ngroups, TB, trec, recw;            // trec: dwords between the records of consecutive taps
     int p0, Wp, W, gap4;
     int gi, lane;
+    int gvoff;                              // the lane's byte offset in an element run: lane * 4, or past the descriptor's range
+                                            // for a lane without pixels (the load returns 0 and requests no cache line)
     bool live;
     unsigned long long *dbg;
 
@@ -286,7 +288,7 @@ struct Loop {
     // Extra elements of the record's slots (steps known at run time: dynamic lane of the record).
     __device__ __forceinline__ void load_slots(uint32_t recv)
     {
-        const int voff = lane * 4;
+        const int voff = gvoff;
         constexpr int sb = 2 * CH + 1;
         const int nslots = (rec_word(recv, 2 * CH) >> 16) & 7;
 #pragma unroll
@@ -336,7 +338,7 @@ struct Loop {
     template <int SA>
     __device__ __forceinline__ void overflow_loop(uint32_t hdr, const float (&w)[KS])
     {
-        const int voff = lane * 4;
+        const int voff = gvoff;
         uint32_t m = hdr & 0xffffu;
 #pragma unroll
         for (int j = 0; j < kDiagSlots; ++j) m &= m - 1;
@@ -374,7 +376,7 @@ struct Loop {
             return;
         }
         const uint32_t rec_new = request_record();
-        const int voff = lane * 4;
+        const int voff = gvoff;
         MFL_SEG(0);
 #ifndef MFL_ABL_NO_CORR
         // corrections first: their slot elements were requested a whole tap ago (right below, in the
@@ -575,7 +577,7 @@ struct Loop {
             rec_pre = request_record();      // tap 1
             rec_req = request_record();      // tap 2
             if constexpr (!BWD) {
-                const int voff = lane * 4;
+                const int voff = gvoff;
 #pragma unroll
                 for (int i = 0; i < CH; ++i) v.A[i] = buf_load(rsrc, voff, rec_word(rec_use, i));
 #pragma unroll
@@ -716,6 +718,14 @@ diag_kernel(DiagGeom g, int epi_rows, int tail_per_group, const float *__restric
             __syncthreads();
         }
     }
+    // A lane whose k pixels all lie past the last b value owns nothing (with many labels NB = L / CK is far below 64:
+    // 36 at 150 labels, 512 x 512, 7 x 7): it requests no elements.  The kernel is bound by cache-line requests, and a
+    // run of 42 lanes touches 2.3 lines where one of 64 touches 3.
+#ifdef MFL_EXP_ALL_LANES_LOAD
+    const int lane_voff = lane * 4;
+#else
+    const int lane_voff = (64 * beta + lane - (KS - 1) < g.NB) ? lane * 4 : (int)0x80000000u;
+#endif
     // pixels (a0 + n, b - n) of this lane: the first has the largest index, the last the smallest.  The k contributors
     // of an element in one line are k pixels (CK - 1) apart, this lane's among them: where that chain may leave the
     // pixel range, the lane counts as an edge lane (Loop::scatter_store).
@@ -729,7 +739,7 @@ diag_kernel(DiagGeom g, int epi_rows, int tail_per_group, const float *__restric
     Loop<CH, KS, NGW, NCS, MODE == 3> loop{qp_out + img_off, copy_stride, edge, g.Cv, ci, st, rsrc,
                                            table + diag_record_index(g, beta, live ? gamma : 0, 0, ci), groups, irsrc, lds,
                                            pw, cw, g.ngroups, g.TB, g.NCS * g.RECW, g.RECW, g.p0, Wp, W, g.gap * 4, gi,
-                                           lane, live, dbg};
+                                           lane, lane_voff, live, dbg};
     MFL_STAMP(1);
     loop.run();
     if constexpr (MODE == 3) return;
