@@ -701,7 +701,22 @@ ring_kernel(RingGeom rg, int lds_floats, int tail_per_group, const float *__rest
             for (int it = 0; it < nit; ++it) {
                 int moff, l, cpos;
                 const bool ok = place(cb0, (it * Cfg::NW + wave) * 32 + p, moff, l, cpos);
-                const uint32_t vq = (uint32_t)(cpos * 4 + h * plane4), vu = (uint32_t)(l * 4 + 4 * h * L4);
+#if defined(MFL_ABL_EPI_UCOAL) || defined(MFL_ABL_EPI_QCOAL)
+                // timing experiments (wrong results): the epilogue's unary / Q accesses as if a wave's 32 pixels were
+                // consecutive and 128-byte aligned in memory
+                const uint32_t fake = ((uint32_t)(blockIdx.x % 4096) * 2048u + (uint32_t)cb0 * 32u + (uint32_t)((it * Cfg::NW + wave) * 32 + p));
+#endif
+#ifdef MFL_ABL_EPI_QCOAL
+                const uint32_t cposq = fake % (uint32_t)(g.plane - 64);
+#else
+                const uint32_t cposq = (uint32_t)cpos;
+#endif
+#ifdef MFL_ABL_EPI_UCOAL
+                const uint32_t lu = fake % (uint32_t)L;
+#else
+                const uint32_t lu = (uint32_t)l;
+#endif
+                const uint32_t vq = (uint32_t)(cposq * 4 + h * plane4), vu = (uint32_t)(lu * 4 + 4 * h * L4);
                 float m[KJ], u[NV];
 #pragma unroll
                 for (int j = 0; j < KJ; ++j) m[j] = bload(rq, vq + (uint32_t)(2 * j * plane4));
@@ -760,7 +775,7 @@ ring_kernel(RingGeom rg, int lds_floats, int tail_per_group, const float *__rest
 #ifdef MFL_ABL_EPI_NOSTORE
                 const uint32_t sq = rsv == 12345.f ? (uint32_t)(cpos * 4 + 4 * h * plane4) : oob;
 #else
-                const uint32_t sq = ok ? (uint32_t)(cpos * 4 + 4 * h * plane4) : oob;
+                const uint32_t sq = ok ? (uint32_t)(cposq * 4 + 4 * h * plane4) : oob;
 #endif
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
