@@ -279,6 +279,9 @@ struct Loop {
         // the CU's requests) instead of asking the L2 again.  Nothing is exchanged at the barrier; every wave of a
         // workgroup walks all K taps, so all of them arrive.
 #ifndef MFL_NO_TAP_BARRIER
+#ifdef MFL_TAP_BARRIER_EVERY
+        if (pos % MFL_TAP_BARRIER_EVERY == 0)       // timing experiment
+#endif
         __builtin_amdgcn_s_barrier();
 #endif
         load_weights(wn, pos + 1);
