@@ -654,7 +654,9 @@ diag_kernel(DiagGeom g, int epi_rows, int tail_per_group, const float *__restric
         const int lc = valid ? (int)l : 0;
         const int y = lc / W, x = lc - y * W;
         const int ibase = y * Wp + x;
-        st.ioff[i] = ibase * 16;
+        // (a slot without a pixel requests nothing: an offset past the descriptor's range returns 0 without a memory
+        // request; its weights are never used)
+        st.ioff[i] = valid ? ibase * 16 : (int)0x80000000u;
         st.lidx[i] = sigma < Cfg::NSLOT ? b_rel * Cfg::RUNP + a_rel : Cfg::SLOTP - 1;
         const F4 c = ip_b[ibase + ctr_off];
         st.cr[i] = c.x; st.cg[i] = c.y; st.cb[i] = c.z;
