@@ -11,8 +11,9 @@ SRC = os.path.join(ROOT, "gpurun_out", ROUND)
 DST = os.path.join(ROOT, "profiles")
 
 for tag in ("c4", "c2", "c5", "ops", "k50", "ctx", "train"):
-    for f in glob.glob(os.path.join(SRC, f"trace_{tag}", "**", "*kernel_stats.csv"), recursive=True):
-        shutil.copy(f, os.path.join(DST, f"{ROUND}_{tag}_kernel_stats.csv"))
+    found = glob.glob(os.path.join(SRC, f"trace_{tag}", "**", "*kernel_stats.csv"), recursive=True)
+    if found:       # (a directory that saw several runs: the newest)
+        shutil.copy(max(found, key=os.path.getmtime), os.path.join(DST, f"{ROUND}_{tag}_kernel_stats.csv"))
     log = os.path.join(SRC, f"trace_{tag}.log")
     if os.path.exists(log):
         lines = [l for l in open(log) if l.startswith("{") or " ms" in l and not l.startswith(("W2", "E2", "I2"))]
