@@ -265,6 +265,33 @@ int mfl_label_context_backward(const float *t, const float *la_w, const float *l
                                size_t workspace_bytes, mfl_stream_t stream);
 
 /*
+ * The same two calls for a caller that keeps what the forward produced (what autograd keeps alive
+ * between DPNModel.forward and loss.backward(), AdvancedModel.py:298-299) instead of paying for the
+ * forward twice:
+ *   mfl_label_context_forward_keep   also writes, per (image, label, pixel), the arg-min mixture
+ *                                    (kept_amin, [B][L][H][W] bytes) and the convolution's value there
+ *                                    before the second affine (kept_cmin, [B][L][H][W] floats);
+ *                                    logq is required, smooth optional
+ *   mfl_label_context_backward_kept  takes logq and those two tensors back and skips the recomputation
+ *                                    (the padded activations, an operand of the weight gradient, are
+ *                                    rebuilt: one elementwise pass)
+ * Results equal those of mfl_label_context_forward / mfl_label_context_backward bit for bit.  Same
+ * workspaces as the calls above.
+ */
+int mfl_label_context_forward_keep(const float *t, const float *la_w, const float *la_b, const float *conv_w,
+                                   const float *conv_b, const float *ga_w, const float *ga_b, const float *unary,
+                                   float *smooth, float *logq, unsigned char *kept_amin, float *kept_cmin, int B, int L,
+                                   int M, int H, int W, int ks, void *workspace, size_t workspace_bytes,
+                                   mfl_stream_t stream);
+int mfl_label_context_backward_kept(const float *t, const float *la_w, const float *la_b, const float *conv_w,
+                                    const float *conv_b, const float *ga_w, const float *ga_b, const float *unary,
+                                    const float *kept_logq, const unsigned char *kept_amin, const float *kept_cmin,
+                                    const float *grad_logq, const float *grad_smooth, float *d_t, float *d_unary,
+                                    float *d_la_w, float *d_la_b, float *d_conv_w, float *d_conv_b, float *d_ga_w,
+                                    float *d_ga_b, int B, int L, int M, int H, int W, int ks, void *workspace,
+                                    size_t workspace_bytes, mfl_stream_t stream);
+
+/*
  * Per-class pixel counts behind the reference's intersection-over-union
  * (DPNModel.calc_intersection_over_union, AdvancedModel.py:448-485):
  *   counts[0][c] = #(pred == c and target == c)    intersection

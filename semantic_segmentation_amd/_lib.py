@@ -39,6 +39,8 @@ SIGNATURES = {
     "mfl_label_context_forward": (_c_int, [_c_void] * 10 + [_c_int] * 6 + [_c_void, _c_size, _c_void]),
     "mfl_label_context_backward_workspace_bytes": (_c_size, [_c_int] * 6),
     "mfl_label_context_backward": (_c_int, [_c_void] * 18 + [_c_int] * 6 + [_c_void, _c_size, _c_void]),
+    "mfl_label_context_forward_keep": (_c_int, [_c_void] * 12 + [_c_int] * 6 + [_c_void, _c_size, _c_void]),
+    "mfl_label_context_backward_kept": (_c_int, [_c_void] * 21 + [_c_int] * 6 + [_c_void, _c_size, _c_void]),
     "mfl_preprocess_workspace_bytes": (_c_size, [_c_int] * 4),
     "mfl_preprocess_rgb8": (_c_int, [_c_void, _c_int, _c_int, _c_void, _c_void, _c_int, _c_void, _c_void, _c_int,
                                      ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _c_void, _c_int, _c_int,

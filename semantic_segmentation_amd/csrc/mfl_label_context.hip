@@ -716,10 +716,9 @@ int launch(const float *planes, const float *w2, const int *koff, int KKp, int C
     return (int)hipGetLastError();
 }
 
-// The forward on a carved workspace: activations into padded planes, weights permuted, fused kernel.
-int context_forward(const ContextWorkspace &ws, char *base, const float *t, const float *la_w, const float *la_b, const float *conv_w,
-                    const float *conv_b, const float *ga_w, const float *ga_b, const float *unary, float *smooth, float *logq,
-                    unsigned char *amin, float *cmin, int B, int L, int M, int H, int W, int ks, hipStream_t st)
+// The activations a = la_w * t + la_b into the workspace's zero-padded planes.
+int context_activations(const ContextWorkspace &ws, char *base, const float *t, const float *la_w, const float *la_b, int B, int L,
+                        int H, int W, int ks, hipStream_t st)
 {
     float *apad = (float *)(base + ws.apad);
     const size_t npad = (size_t)B * L * ws.Hp * ws.Wp + 128;
@@ -728,6 +727,19 @@ int context_forward(const ContextWorkspace &ws, char *base, const float *t, cons
     const unsigned g1 = (unsigned)((n + 255) / 256 < 65535u * 8u ? (n + 255) / 256 : 65535u * 8u);
     hipLaunchKernelGGL(label_context_activation_kernel, dim3(g1), dim3(256), 0, st, t, la_w, la_b, apad, B, L, H, W, ws.Hp, ws.Wp,
                        ks / 2);
+    return (int)hipGetLastError();
+}
+
+// The forward on a carved workspace: activations into padded planes, weights permuted, fused kernel.
+int context_forward(const ContextWorkspace &ws, char *base, const float *t, const float *la_w, const float *la_b, const float *conv_w,
+                    const float *conv_b, const float *ga_w, const float *ga_b, const float *unary, float *smooth, float *logq,
+                    unsigned char *amin, float *cmin, int B, int L, int M, int H, int W, int ks, hipStream_t st)
+{
+    float *apad = (float *)(base + ws.apad);
+    {
+        const int rc = context_activations(ws, base, t, la_w, la_b, B, L, H, W, ks, st);
+        if (rc) return rc;
+    }
     // rows of the GEMM: 32 per mixture (the min over the mixtures is then register-wise), or, where that saves a block of
     // 32 rows, the output channels packed (21 labels x 5 mixtures: 4 blocks instead of 5)
     const int nblk = (L * M + 31) / 32;
@@ -818,12 +830,32 @@ extern "C" int mfl_label_context_forward(const float *t, const float *la_w, cons
                            M, H, W, ks, (hipStream_t)stream);
 }
 
-extern "C" int mfl_label_context_backward(const float *t, const float *la_w, const float *la_b, const float *conv_w,
-                                          const float *conv_b, const float *ga_w, const float *ga_b, const float *unary,
-                                          const float *grad_logq, const float *grad_smooth, float *d_t, float *d_unary,
-                                          float *d_la_w, float *d_la_b, float *d_conv_w, float *d_conv_b, float *d_ga_w,
-                                          float *d_ga_b, int B, int L, int M, int H, int W, int ks, void *workspace,
-                                          size_t workspace_bytes, mfl_stream_t stream)
+extern "C" int mfl_label_context_forward_keep(const float *t, const float *la_w, const float *la_b, const float *conv_w,
+                                              const float *conv_b, const float *ga_w, const float *ga_b, const float *unary,
+                                              float *smooth, float *logq, unsigned char *kept_amin, float *kept_cmin, int B, int L,
+                                              int M, int H, int W, int ks, void *workspace, size_t workspace_bytes,
+                                              mfl_stream_t stream)
+{
+    if (!t || !conv_w || !unary || !logq || !kept_amin || !kept_cmin) return MFL_ERR_INVALID_ARGUMENT;
+    if ((la_w == nullptr) != (la_b == nullptr) || (ga_w == nullptr) != (ga_b == nullptr)) return MFL_ERR_INVALID_ARGUMENT;
+    if (B <= 0 || H <= 0 || W <= 0 || !context_supported(L, M, ks)) return MFL_ERR_INVALID_ARGUMENT;
+    if ((long long)B * L * (H + ks - 1) * (W + ks - 1) >= (1LL << 31)) return MFL_ERR_TOO_LARGE;
+    const ContextWorkspace ws = context_carve(B, L, M, H, W, ks);
+    if (!workspace || workspace_bytes < ws.total) return MFL_ERR_WORKSPACE;
+    return context_forward(ws, (char *)workspace, t, la_w, la_b, conv_w, conv_b, ga_w, ga_b, unary, smooth, logq, kept_amin, kept_cmin,
+                           B, L, M, H, W, ks, (hipStream_t)stream);
+}
+
+namespace {
+
+// kept_*: logq, the arg-min mixture and the convolution's value there as mfl_label_context_forward_keep wrote them, or all
+// NULL: the forward is run again into the workspace.
+int context_backward(const float *t, const float *la_w, const float *la_b, const float *conv_w, const float *conv_b,
+                     const float *ga_w, const float *ga_b, const float *unary, const float *kept_logq,
+                     const unsigned char *kept_amin, const float *kept_cmin, const float *grad_logq, const float *grad_smooth,
+                     float *d_t, float *d_unary, float *d_la_w, float *d_la_b, float *d_conv_w, float *d_conv_b, float *d_ga_w,
+                     float *d_ga_b, int B, int L, int M, int H, int W, int ks, void *workspace, size_t workspace_bytes,
+                     mfl_stream_t stream)
 {
     if (!t || !conv_w || !unary || (!grad_logq && !grad_smooth) || !d_t || !d_unary || !d_conv_w) return MFL_ERR_INVALID_ARGUMENT;
     if ((la_w == nullptr) != (la_b == nullptr) || (ga_w == nullptr) != (ga_b == nullptr)) return MFL_ERR_INVALID_ARGUMENT;
@@ -838,20 +870,29 @@ extern "C" int mfl_label_context_backward(const float *t, const float *la_w, con
     hipStream_t st = (hipStream_t)stream;
     const int HW = H * W, p = ks / 2, LM = L * M;
     const size_t gplane = (size_t)ws.HpG * ws.WpG;
-    float *logq = (float *)(base + ws.logq), *cmin = (float *)(base + ws.cmin), *gpad = (float *)(base + ws.gpad);
+    float *gpad = (float *)(base + ws.gpad);
     float *da = (float *)(base + ws.da);
-    unsigned char *amin = (unsigned char *)(base + ws.amin);
-    // the forward again, keeping the arg-min mixture and the convolution's value there
-    int rc = context_forward(ws, base, t, la_w, la_b, conv_w, conv_b, ga_w, ga_b, unary, nullptr, logq, amin, cmin, B, L, M, H, W, ks, st);
+    const float *logq = kept_logq, *cmin = kept_cmin;
+    const unsigned char *amin = kept_amin;
+    int rc;
+    if (kept_logq) {
+        // the caller kept what the forward produced: only the padded activations (the weight gradient's operand) are rebuilt
+        rc = context_activations(ws, base, t, la_w, la_b, B, L, H, W, ks, st);
+    } else {
+        // the forward again, keeping the arg-min mixture and the convolution's value there
+        float *lq = (float *)(base + ws.logq), *cm = (float *)(base + ws.cmin);
+        unsigned char *am = (unsigned char *)(base + ws.amin);
+        rc = context_forward(ws, base, t, la_w, la_b, conv_w, conv_b, ga_w, ga_b, unary, nullptr, lq, am, cm, B, L, M, H, W, ks, st);
+        logq = lq; cmin = cm; amin = am;
+    }
     if (rc) return rc;
     MFL_CHECK_HIP(hipMemsetAsync(gpad, 0, ((size_t)B * LM * gplane + 128) * 4, st));
     if (ga_w) {
         MFL_CHECK_HIP(hipMemsetAsync(d_ga_w, 0, (size_t)LM * HW * 4, st));
         MFL_CHECK_HIP(hipMemsetAsync(d_ga_b, 0, (size_t)LM * HW * 4, st));
     }
-    hipLaunchKernelGGL(context_pre_kernel, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, st, grad_logq, grad_smooth, (const float *)logq,
-                       unary, (const unsigned char *)amin, (const float *)cmin, ga_w, gpad, d_unary, d_ga_w, d_ga_b, B, L, M, H, W, ws.HpG,
-                       ws.WpG, p);
+    hipLaunchKernelGGL(context_pre_kernel, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, st, grad_logq, grad_smooth, logq, unary, amin,
+                       cmin, ga_w, gpad, d_unary, d_ga_w, d_ga_b, B, L, M, H, W, ws.HpG, ws.WpG, p);
     if (d_conv_b) {
         // (the per-image sums borrow the start of the weight gradient's partial-sum buffer, which is written later)
         float *bpart = (float *)(base + ws.part);
@@ -889,4 +930,32 @@ extern "C" int mfl_label_context_backward(const float *t, const float *la_w, con
                            d_conv_w, LM, nb, ws.KK, ws.ncb, ws.nsl);
     }
     return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int mfl_label_context_backward(const float *t, const float *la_w, const float *la_b, const float *conv_w,
+                                          const float *conv_b, const float *ga_w, const float *ga_b, const float *unary,
+                                          const float *grad_logq, const float *grad_smooth, float *d_t, float *d_unary,
+                                          float *d_la_w, float *d_la_b, float *d_conv_w, float *d_conv_b, float *d_ga_w,
+                                          float *d_ga_b, int B, int L, int M, int H, int W, int ks, void *workspace,
+                                          size_t workspace_bytes, mfl_stream_t stream)
+{
+    return context_backward(t, la_w, la_b, conv_w, conv_b, ga_w, ga_b, unary, nullptr, nullptr, nullptr, grad_logq, grad_smooth, d_t,
+                            d_unary, d_la_w, d_la_b, d_conv_w, d_conv_b, d_ga_w, d_ga_b, B, L, M, H, W, ks, workspace, workspace_bytes,
+                            stream);
+}
+
+extern "C" int mfl_label_context_backward_kept(const float *t, const float *la_w, const float *la_b, const float *conv_w,
+                                               const float *conv_b, const float *ga_w, const float *ga_b, const float *unary,
+                                               const float *kept_logq, const unsigned char *kept_amin, const float *kept_cmin,
+                                               const float *grad_logq, const float *grad_smooth, float *d_t, float *d_unary,
+                                               float *d_la_w, float *d_la_b, float *d_conv_w, float *d_conv_b, float *d_ga_w,
+                                               float *d_ga_b, int B, int L, int M, int H, int W, int ks, void *workspace,
+                                               size_t workspace_bytes, mfl_stream_t stream)
+{
+    if (!kept_logq || !kept_amin || !kept_cmin) return MFL_ERR_INVALID_ARGUMENT;
+    return context_backward(t, la_w, la_b, conv_w, conv_b, ga_w, ga_b, unary, kept_logq, kept_amin, kept_cmin, grad_logq, grad_smooth,
+                            d_t, d_unary, d_la_w, d_la_b, d_conv_w, d_conv_b, d_ga_w, d_ga_b, B, L, M, H, W, ks, workspace,
+                            workspace_bytes, stream);
 }

@@ -111,11 +111,19 @@ class MeanFieldLocal(nn.Module):
 
 
 class _LabelContextFunction(torch.autograd.Function):
-    """(logq, smooth) = the fused label-context kernel; backward by mfl_label_context_backward (the forward is
-    recomputed there, so nothing but the inputs is kept)."""
+    """(logq, smooth) = the fused label-context kernel; backward by mfl_label_context_backward_kept: besides the inputs,
+    logq, the arg-min mixture (one byte per label and pixel) and the convolution's value there are kept, as autograd
+    keeps the reference's intermediates alive (AdvancedModel.py:298-299), so the convolution is not run twice.
+    keep_forward = False trades that memory (9 bytes per label and pixel) for a recomputation inside the backward."""
+    keep_forward = True
 
     @staticmethod
     def forward(ctx, t, unary, la_w, la_b, conv_w, conv_b, ga_w, ga_b):
+        if _LabelContextFunction.keep_forward:
+            logq, smooth, (amin, cmin) = ops.label_context_forward(t, conv_w, unary, conv_b=conv_b, la_w=la_w, la_b=la_b,
+                                                                   ga_w=ga_w, ga_b=ga_b, want_smooth=True, keep=True)
+            ctx.save_for_backward(t, unary, la_w, la_b, conv_w, conv_b, ga_w, ga_b, logq, amin, cmin)
+            return logq, smooth
         ctx.save_for_backward(t, unary, la_w, la_b, conv_w, conv_b, ga_w, ga_b)
         logq, smooth = ops.label_context_forward(t, conv_w, unary, conv_b=conv_b, la_w=la_w, la_b=la_b, ga_w=ga_w, ga_b=ga_b,
                                                  want_smooth=True)
@@ -124,10 +132,12 @@ class _LabelContextFunction(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_logq, grad_smooth):
-        t, unary, la_w, la_b, conv_w, conv_b, ga_w, ga_b = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        t, unary, la_w, la_b, conv_w, conv_b, ga_w, ga_b = saved[:8]
+        kept = tuple(saved[8:]) if len(saved) > 8 else None
         # an output nobody used arrives as zeros (materialised): passing it along costs one more read per element
         g = ops.label_context_backward(t, conv_w, unary, grad_logq=grad_logq, grad_smooth=grad_smooth, conv_b=conv_b,
-                                       la_w=la_w, la_b=la_b, ga_w=ga_w, ga_b=ga_b)
+                                       la_w=la_w, la_b=la_b, ga_w=ga_w, ga_b=ga_b, kept=kept)
         order = ("d_t", "d_unary", "d_la_w", "d_la_b", "d_conv_w", "d_conv_b", "d_ga_w", "d_ga_b")
         return tuple(g[key] if ctx.needs_input_grad[i] else None for i, key in enumerate(order))
 

@@ -168,10 +168,12 @@ def argmax_labels(logq: torch.Tensor) -> torch.Tensor:
 
 
 def label_context_forward(t, conv_w, unary, conv_b=None, la_w=None, la_b=None, ga_w=None, ga_b=None, mixtures=None,
-                          want_smooth=False):
+                          want_smooth=False, keep=False):
     """DPNModel.forward phases 3-4 behind the local convolution (AdvancedModel.py:223, 232-244): per-pixel affine,
     Conv2d(L -> L*M, ks x ks, pad ks//2), per-pixel affine, min over the M mixtures, then
-    LogSoftmax(log_softmax(unary) - smooth).  Returns logq, or (logq, smooth) with want_smooth."""
+    LogSoftmax(log_softmax(unary) - smooth).  Returns logq, or (logq, smooth) with want_smooth; with keep also the pair
+    (arg-min mixture as uint8, the convolution's value there) that label_context_backward(kept=...) takes back instead of
+    running the forward again."""
     _lib.require_device(t, conv_w, unary, conv_b, la_w, la_b, ga_w, ga_b)
     t, conv_w, unary, conv_b = _c(t), _c(conv_w), _c(unary), _c(conv_b)
     la_w, la_b, ga_w, ga_b = _c(la_w), _c(la_b), _c(ga_w), _c(ga_b)
@@ -198,6 +200,14 @@ def label_context_forward(t, conv_w, unary, conv_b=None, la_w=None, la_b=None, g
     smooth = torch.empty_like(t) if want_smooth else None
     with torch.cuda.device(t.device):
         ws = torch.empty(n, dtype=torch.uint8, device=t.device)
+        if keep:
+            amin = torch.empty(t.shape, dtype=torch.uint8, device=t.device)
+            cmin = torch.empty_like(t)
+            _lib.check(lib.mfl_label_context_forward_keep(ptr(t), ptr(la_w), ptr(la_b), ptr(conv_w), ptr(conv_b), ptr(ga_w),
+                                                          ptr(ga_b), ptr(unary), ptr(smooth), ptr(logq), ptr(amin), ptr(cmin),
+                                                          B, L, M, H, W, ks, ptr(ws), n, stream_of(t)),
+                       "mfl_label_context_forward_keep")
+            return (logq, smooth, (amin, cmin)) if want_smooth else (logq, (amin, cmin))
         _lib.check(lib.mfl_label_context_forward(ptr(t), ptr(la_w), ptr(la_b), ptr(conv_w), ptr(conv_b), ptr(ga_w), ptr(ga_b),
                                                  ptr(unary), ptr(smooth), ptr(logq), B, L, M, H, W, ks, ptr(ws), n,
                                                  stream_of(t)), "mfl_label_context_forward")
@@ -205,10 +215,11 @@ def label_context_forward(t, conv_w, unary, conv_b=None, la_w=None, la_b=None, g
 
 
 def label_context_backward(t, conv_w, unary, grad_logq=None, grad_smooth=None, conv_b=None, la_w=None, la_b=None,
-                           ga_w=None, ga_b=None):
+                           ga_w=None, ga_b=None, kept=None):
     """Gradients of label_context_forward (autograd through AdvancedModel.py:223, 232-244; loss.backward(),
     AdvancedModel.py:299) for dL/dlogq and / or dL/dsmooth.  Returns a dict with d_t, d_unary, d_conv_w and, for the
-    optional inputs that were given, d_conv_b, d_la_w, d_la_b, d_ga_w, d_ga_b (shaped like the inputs)."""
+    optional inputs that were given, d_conv_b, d_la_w, d_la_b, d_ga_w, d_ga_b (shaped like the inputs).
+    kept: (logq, amin, cmin) of label_context_forward(..., keep=True) on the same inputs: the forward is not run again."""
     _lib.require_device(t, conv_w, unary, grad_logq, grad_smooth, conv_b, la_w, la_b, ga_w, ga_b)
     t, conv_w, unary, conv_b = _c(t), _c(conv_w), _c(unary), _c(conv_b)
     la_w, la_b, ga_w, ga_b, grad_logq, grad_smooth = _c(la_w), _c(la_b), _c(ga_w), _c(ga_b), _c(grad_logq), _c(grad_smooth)
@@ -233,6 +244,22 @@ def label_context_backward(t, conv_w, unary, grad_logq=None, grad_smooth=None, c
     like = lambda v: None if v is None else torch.empty_like(v)
     out = {"d_t": torch.empty_like(t), "d_unary": torch.empty_like(t), "d_conv_w": torch.empty_like(conv_w),
            "d_conv_b": like(conv_b), "d_la_w": like(la_w), "d_la_b": like(la_b), "d_ga_w": like(ga_w), "d_ga_b": like(ga_b)}
+    if kept is not None:
+        k_logq, k_amin, k_cmin = kept
+        _lib.require_device(k_logq, k_cmin)
+        if not k_amin.is_cuda or k_amin.device != t.device:
+            raise RuntimeError("kept tensors must live on the device of t")
+        if k_logq.shape != t.shape or k_cmin.shape != t.shape or k_amin.shape != t.shape or k_amin.dtype != torch.uint8:
+            raise RuntimeError("kept must be (logq float32, amin uint8, cmin float32), each shaped like t")
+        k_logq, k_amin, k_cmin = _c(k_logq), k_amin.contiguous(), _c(k_cmin)
+        with torch.cuda.device(t.device):
+            ws = torch.empty(n, dtype=torch.uint8, device=t.device)
+            _lib.check(lib.mfl_label_context_backward_kept(
+                ptr(t), ptr(la_w), ptr(la_b), ptr(conv_w), ptr(conv_b), ptr(ga_w), ptr(ga_b), ptr(unary), ptr(k_logq), ptr(k_amin),
+                ptr(k_cmin), ptr(grad_logq), ptr(grad_smooth), ptr(out["d_t"]), ptr(out["d_unary"]), ptr(out["d_la_w"]),
+                ptr(out["d_la_b"]), ptr(out["d_conv_w"]), ptr(out["d_conv_b"]), ptr(out["d_ga_w"]), ptr(out["d_ga_b"]), B, L, M, H, W,
+                ks, ptr(ws), n, stream_of(t)), "mfl_label_context_backward_kept")
+        return out
     with torch.cuda.device(t.device):
         ws = torch.empty(n, dtype=torch.uint8, device=t.device)
         _lib.check(lib.mfl_label_context_backward(

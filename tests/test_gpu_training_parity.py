@@ -451,3 +451,44 @@ def test_local_backward_many_labels_bitwise_reproducible(S, oracle):
     rdx, rdpw, rdcw = oracle.local_backward(x, 0.3, -0.7, 5, dy, img=img)
     assert_close(host(a[0]), rdx, RTOL, "dx")
     assert abs(float(a[1][0]) - rdpw) <= 2e-4 * abs(rdpw) and abs(float(a[1][1]) - rdcw) <= 2e-4 * abs(rdcw)
+
+
+@pytest.mark.parametrize("shape", [(2, 21, 5, 40, 70, 9), (1, 7, 2, 33, 31, 3), (2, 32, 3, 24, 40, 5)])
+def test_label_context_backward_from_kept_forward_equals_the_recomputing_one(S, shape):
+    """mfl_label_context_forward_keep + mfl_label_context_backward_kept (the forward's log-marginals, arg-min mixture and
+    convolution value handed back) against mfl_label_context_forward + mfl_label_context_backward (forward run again
+    inside): the same kernels on the same values, so every output is equal bit for bit; and LabelContext under autograd
+    gives the same gradients with either setting of keep_forward."""
+    from semantic_segmentation_amd.meanfield import _LabelContextFunction
+    B, L, M, H, W, ks = shape
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    t, unary, G, Gs = rnd(B, L, H, W), rnd(B, L, H, W), rnd(B, L, H, W), rnd(B, L, H, W)
+    conv_w, conv_b = 0.1 * rnd(L * M, L, ks, ks), rnd(L * M)
+    la_w, la_b, ga_w, ga_b = rnd(1, L, H, W), rnd(1, L, H, W), rnd(1, L * M, H, W), rnd(1, L * M, H, W)
+    kw = dict(conv_b=conv_b, la_w=la_w, la_b=la_b, ga_w=ga_w, ga_b=ga_b)
+    logq0, smooth0 = S.ops.label_context_forward(t, conv_w, unary, want_smooth=True, **kw)
+    logq1, smooth1, (amin, cmin) = S.ops.label_context_forward(t, conv_w, unary, want_smooth=True, keep=True, **kw)
+    assert torch.equal(logq0, logq1) and torch.equal(smooth0, smooth1)
+    assert amin.dtype == torch.uint8 and int(amin.max()) < M
+    a = S.ops.label_context_backward(t, conv_w, unary, grad_logq=G, grad_smooth=Gs, **kw)
+    b = S.ops.label_context_backward(t, conv_w, unary, grad_logq=G, grad_smooth=Gs, kept=(logq1, amin, cmin), **kw)
+    for key in a:
+        assert torch.equal(a[key], b[key]), key
+    mod = S.LabelContext(H, W, L, M, ks).cuda()
+    with torch.no_grad():
+        for p_ in mod.parameters():
+            p_.copy_(0.1 * torch.randn(p_.shape, device="cuda", generator=g))
+    grads = []
+    for keep in (True, False):
+        _LabelContextFunction.keep_forward = keep
+        try:
+            tt = t.clone().requires_grad_(True)
+            mod.zero_grad()
+            lq, sm = mod(tt, unary, want_smooth=True)
+            ((lq * G).sum() + (sm * Gs).sum()).backward()
+            grads.append([tt.grad.clone()] + [p_.grad.clone() for p_ in mod.parameters()])
+        finally:
+            _LabelContextFunction.keep_forward = True
+    for x, y in zip(*grads):
+        assert torch.equal(x, y)

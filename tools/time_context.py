@@ -31,3 +31,13 @@ bw()
 ms = timed(bw)
 print(f"label context backward (forward recomputed + data gradient + weight gradient): {ms:.3f} ms  "
       f"{3 * flops / ms / 1e9:.1f} TFLOP/s over its three convolution-sized GEMMs")
+with torch.no_grad():
+    lq, (am, cm) = S.ops.label_context_forward(t, conv.weight.detach(), unary, conv_b=conv.bias.detach(),
+                                               la_w=mod.local_activation_function.weight.detach(), la_b=mod.local_activation_function.bias.detach(),
+                                               ga_w=mod.global_activation_function.weight.detach(), ga_b=mod.global_activation_function.bias.detach(), keep=True)
+bk = lambda: S.ops.label_context_backward(t, conv.weight.detach(), unary, grad_logq=G, conv_b=conv.bias.detach(),
+                                          la_w=mod.local_activation_function.weight.detach(), la_b=mod.local_activation_function.bias.detach(),
+                                          ga_w=mod.global_activation_function.weight.detach(), ga_b=mod.global_activation_function.bias.detach(),
+                                          kept=(lq, am, cm))
+bk()
+print(f"label context backward from a kept forward (log-marginals, arg-min mixture, convolution value handed back): {timed(bk):.3f} ms")
