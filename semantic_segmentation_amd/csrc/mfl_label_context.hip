@@ -372,6 +372,10 @@ label_context_kernel(const float *__restrict__ apad, const float *__restrict__ w
 //   gpad[b][m* L + l][y + p][x + p] = ga_w * d smooth (the planes were zeroed: the other mixtures stay 0);
 //   d ga_w[m* L + l][pixel] += d smooth * conv value there, d ga_b += d smooth (zeroed by the caller).
 // grad_logq / grad_smooth: either may be NULL (not both).
+// LP: the label count rounded up to a multiple of 8 (one build each): a thread keeps the pixel's gradient, unary and
+// log-marginal of every label in registers, so each is loaded once and all loads of an image are in flight together
+// (a first version walked the labels three times with loads inside each loop: 1.8 ms at 21 labels, 512 x 512, batch 8).
+template <int LP>
 __global__ void __launch_bounds__(256)
 context_pre_kernel(const float *__restrict__ grad_logq, const float *__restrict__ grad_smooth, const float *__restrict__ logq,
                    const float *__restrict__ unary, const unsigned char *__restrict__ amin, const float *__restrict__ cmin,
@@ -383,34 +387,49 @@ context_pre_kernel(const float *__restrict__ grad_logq, const float *__restrict_
     if (pix >= HW) return;
     const int y = pix / W, x = pix - y * W;
     const size_t gplane = (size_t)HpG * WpG;
+    const size_t gpix = (size_t)(y + p) * WpG + x + p;
     for (int b = 0; b < B; ++b) {
         const size_t base = (size_t)b * L * HW + pix;
-        float sg = 0.f, mx = -INFINITY;
-        for (int l = 0; l < L; ++l) {
-            if (grad_logq) sg += grad_logq[base + (size_t)l * HW];
-            mx = fmaxf(mx, unary[base + (size_t)l * HW]);
+        float g[LP], u[LP], e[LP], gs[LP], cm[LP];
+        int am[LP];
+#pragma unroll
+        for (int l = 0; l < LP; ++l) {
+            const size_t o = base + (size_t)(l < L ? l : L - 1) * HW;
+            g[l] = (grad_logq && l < L) ? grad_logq[o] : 0.f;
+            u[l] = l < L ? unary[o] : -INFINITY;
+            e[l] = (grad_logq && l < L) ? logq[o] : -INFINITY;
+            gs[l] = (grad_smooth && l < L) ? grad_smooth[o] : 0.f;
+            am[l] = amin[o];
+            cm[l] = cmin[o];
         }
+        float sg = 0.f, mx = -INFINITY;
+#pragma unroll
+        for (int l = 0; l < LP; ++l) { sg += g[l]; mx = fmaxf(mx, u[l]); }
         float sdz = 0.f, se = 0.f;
-        for (int l = 0; l < L; ++l) {
-            const size_t o = base + (size_t)l * HW;
-            if (grad_logq) sdz += grad_logq[o] - __expf(logq[o]) * sg;
-            se += __expf(unary[o] - mx);
+#pragma unroll
+        for (int l = 0; l < LP; ++l) {
+            g[l] = g[l] - __expf(e[l]) * sg;           // dz (0 past L: exp(-inf) = 0)
+            u[l] = __expf(u[l] - mx);
+            sdz += g[l];
+            se += u[l];
         }
         const float rse = 1.f / se;
-        for (int l = 0; l < L; ++l) {
-            const size_t o = base + (size_t)l * HW;
-            const float dz = grad_logq ? grad_logq[o] - __expf(logq[o]) * sg : 0.f;
-            d_unary[o] = dz - __expf(unary[o] - mx) * rse * sdz;
-            const float ds = (grad_smooth ? grad_smooth[o] : 0.f) - dz;
-            const int oc = (int)amin[o] * L + l;
-            const size_t oa = (size_t)oc * HW + pix;
-            float dconv = ds;
-            if (ga_w) {
-                dconv = ga_w[oa] * ds;
-                d_ga_w[oa] = fmaf(ds, cmin[o], d_ga_w[oa]);
-                d_ga_b[oa] += ds;
+#pragma unroll
+        for (int l = 0; l < LP; ++l) {
+            if (l < L) {
+                const size_t o = base + (size_t)l * HW;
+                d_unary[o] = g[l] - u[l] * rse * sdz;
+                const float ds = gs[l] - g[l];
+                const int oc = am[l] * L + l;
+                const size_t oa = (size_t)oc * HW + pix;
+                float dconv = ds;
+                if (ga_w) {
+                    dconv = ga_w[oa] * ds;
+                    d_ga_w[oa] = fmaf(ds, cm[l], d_ga_w[oa]);
+                    d_ga_b[oa] += ds;
+                }
+                gpad[((size_t)b * L * M + oc) * gplane + gpix] = dconv;
             }
-            gpad[((size_t)b * L * M + oc) * gplane + (size_t)(y + p) * WpG + x + p] = dconv;
         }
     }
 }
@@ -891,8 +910,15 @@ int context_backward(const float *t, const float *la_w, const float *la_b, const
         MFL_CHECK_HIP(hipMemsetAsync(d_ga_w, 0, (size_t)LM * HW * 4, st));
         MFL_CHECK_HIP(hipMemsetAsync(d_ga_b, 0, (size_t)LM * HW * 4, st));
     }
-    hipLaunchKernelGGL(context_pre_kernel, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, st, grad_logq, grad_smooth, logq, unary, amin,
-                       cmin, ga_w, gpad, d_unary, d_ga_w, d_ga_b, B, L, M, H, W, ws.HpG, ws.WpG, p);
+#define MFL_CTX_PRE(LPV)                                                                                                             \
+    case LPV:                                                                                                                        \
+        hipLaunchKernelGGL(context_pre_kernel<LPV>, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, st, grad_logq, grad_smooth, logq, \
+                           unary, amin, cmin, ga_w, gpad, d_unary, d_ga_w, d_ga_b, B, L, M, H, W, ws.HpG, ws.WpG, p);                  \
+        break;
+    switch ((L + 7) / 8 * 8) {
+        MFL_CTX_PRE(8) MFL_CTX_PRE(16) MFL_CTX_PRE(24) MFL_CTX_PRE(32)
+    }
+#undef MFL_CTX_PRE
     if (d_conv_b) {
         // (the per-image sums borrow the start of the weight gradient's partial-sum buffer, which is written later)
         float *bpart = (float *)(base + ws.part);
