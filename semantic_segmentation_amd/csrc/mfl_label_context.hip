@@ -26,8 +26,8 @@
 //   pre          dz = G - exp(logq) * sum G, d unary, d smooth = -dz (+ a caller's gradient of smooth), the gradient of
 //                the convolution's output (non-zero in the arg-min mixture only) into zero-padded planes, d ga_w, d ga_b
 //   bias         d conv_b = plane sums of that gradient
-//   data         d a = Conv2d(L*M -> L) of those planes with the flipped, transposed weights: the same implicit GEMM,
-//                one block of 32 rows (context_conv_kernel<1, plain epilogue>)
+//   data         d a = Conv2d(L*M -> L) of those planes with the flipped, transposed weights: an implicit GEMM with one
+//                block of 32 rows, both operands staged through LDS plane by plane (context_dgrad_kernel)
 //   affine       d t = la_w * d a, d la_w = sum_b d a * t, d la_b = sum_b d a
 //   weights      d conv_w[o][i][ky][kx] = sum over pixels of (gradient plane o) * (padded activation plane i shifted by
 //                the tap): a GEMM [L*M x pixels] . [pixels x L*k*k] on the same instruction, pixels split into slices
@@ -50,11 +50,9 @@ namespace {
 typedef float f16v __attribute__((ext_vector_type(16)));
 
 constexpr int kWavesPerGroup = 4;
-// Tiles (32 pixels each) per wave: one for the fused forward (two tiles per wave, 160 accumulators, left one wave per SIMD:
-// 13.9 instead of 11.3 ms); four for the plain convolution of the data gradient, whose single block of rows would
-// otherwise issue one matrix instruction per weight read from LDS (15.1 ms with one tile per wave).
-template <int MODE>
-struct TilesPerWave { static constexpr int value = MODE == 1 ? 4 : 1; };
+// Tiles (32 pixels each) per wave of the fused forward: one (two tiles per wave, 160 accumulators, left one wave per
+// SIMD: 13.9 instead of 11.3 ms).
+constexpr int kTilesPerWave = 1;
 constexpr int kChunk = 32;          // K-values of the weights per LDS stage (even)
 constexpr int kMaxMixtures = 5;     // mixtures per label (the entry points reject more)
 constexpr int kAhead = 4;           // k-steps whose activation loads are in flight together
@@ -104,11 +102,10 @@ __global__ void label_context_weights_kernel(const float *__restrict__ conv_w, f
 
 // MODE 0: the fused forward epilogue (optionally keeping the arg-min mixture `amin` and the convolution's value
 //         there `cmin`, for the backward)
-// MODE 1: plain convolution: out[b][l][y][x] = accumulator (M = 1), written to `smooth`
 // MODE 2: the fused forward with packed rows: M counts blocks of 32 rows, row r = output channel r; the mixtures of a
 //         label then sit in different lanes and registers, so the accumulators pass through a per-wave LDS tile
 //         before the min over the `mixtures` mixtures.  21 labels x 5 mixtures: 4 blocks instead of 5.
-// Cin: channels of the padded input planes (L for the forward; L*M for the data gradient, whose rows are the L labels)
+// Cin: channels of the padded input planes (L)
 // (two waves per SIMD: the epilogue of one overlaps the matrix instructions of the other)
 template <int M, int MODE>
 __global__ void __launch_bounds__(64 * kWavesPerGroup, 2)
@@ -119,7 +116,6 @@ label_context_kernel(const float *__restrict__ apad, const float *__restrict__ w
                      int W, int Wp, int plane, int KKp, int tiles_per_row, int mixtures)
 {
     constexpr int R = 32 * M;
-    constexpr int kTilesPerWave = TilesPerWave<MODE>::value;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // two stages of weights [2][kChunk][R], then the tap offsets [KKp]
     int *ko = reinterpret_cast<int *>(lds + 2 * kChunk * R);
@@ -242,18 +238,6 @@ label_context_kernel(const float *__restrict__ apad, const float *__restrict__ w
     }
 #endif
 
-    if constexpr (MODE == 1) {
-#pragma unroll
-        for (int tt = 0; tt < kTilesPerWave; ++tt) {
-            if (!ok[tt]) continue;
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int l = 8 * (v / 4) + 4 * h + (v % 4);
-                if (l < L) smooth[((size_t)img[tt] * L + l) * HW + pixl[tt]] = d[tt][0][v];
-            }
-        }
-        return;
-    }
     auto other_half = [&](float v) {
         return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, v)));
     };
@@ -464,25 +448,142 @@ __global__ void context_bias_grad_sum_kernel(const float *__restrict__ part, flo
 }
 
 // Weights of the data gradient: d a = Conv2d(L*M -> L, ks x ks, pad ks/2) of the gradient planes with
-// wt[kk][i] = conv_w[o][i][ks-1-ky][ks-1-kx], kk = (o*ks + ky)*ks + kx (zero for i >= L and kk >= KK2);
-// koff2[kk] = offset of tap kk in the gradient planes.
-__global__ void context_dgrad_weights_kernel(const float *__restrict__ conv_w, float *__restrict__ wt, int *__restrict__ koff2, int L,
-                                             int LM, int ks, int KK2, int KK2p, int gplane, int WpG)
+// wt[kk][i] = conv_w[o][i][ks-1-ky][ks-1-kx], kk = (o*ks + ky)*ks + kx (zero for i >= L and kk >= KK2)
+__global__ void context_dgrad_weights_kernel(const float *__restrict__ conv_w, float *__restrict__ wt, int L, int LM, int ks, int KK2,
+                                             int KK2p)
 {
     const size_t n = (size_t)KK2p * 32;
     const int kk2 = ks * ks;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
         const int kk = (int)(idx >> 5), i = (int)(idx & 31);
         float v = 0.f;
-        int off = 0;
-        if (kk < KK2) {
+        if (kk < KK2 && i < L) {
             const int o = kk / kk2, rem = kk - o * kk2, ky = rem / ks, kx = rem - ky * ks;
-            if (i < L) v = conv_w[(((size_t)o * L + i) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)];
-            off = o * gplane + ky * WpG + kx;
+            v = conv_w[(((size_t)o * L + i) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)];
         }
         wt[idx] = v;
-        if (i == 0) koff2[kk] = off;
     }
+}
+
+// Data gradient: d a[i][y][x] = sum over (o, ky, kx) of wt[(o, ky, kx)][i] * gpad[o][y + ky][x + kx], a convolution
+// L*M -> L channels whose GEMM has ONE block of 32 rows (the L labels), so an operand fetched from memory would feed a
+// single matrix instruction.  A workgroup of four waves therefore takes a strip of 512 pixels of an image row (four
+// 32-pixel tiles per wave) and walks the L*M gradient planes: per plane the k rows x (512 + k - 1) columns the strip's
+// windows reach and the plane's k*k x 32 weights go through LDS (coalesced loads, the next plane's in registers while this
+// one is multiplied, two LDS stages, one barrier per plane), and every matrix instruction reads both operands from there:
+// lane (p, h) supplies row / pixel p at tap 2j + h.  An odd tap count gets one more tap of zero weights.
+// (The first version ran the forward's kernel with the pixels' values loaded from global memory, one load per matrix
+// instruction: 11.1 ms at 21 labels, 5 mixtures, 9 x 9, 512 x 512, batch 8.)
+constexpr int kDgTilesPerWave = 4;
+constexpr int kDgStrip = kWavesPerGroup * kDgTilesPerWave * 32;      // pixels of a strip
+
+template <int KS>
+struct DgCfg {
+    static constexpr int PW = kDgStrip + KS - 1;                     // columns of a plane's patch
+    static constexpr int NP = KS * PW;                               // ... its elements
+    static constexpr int KT = KS * KS, KTP = (KT + 1) / 2 * 2;       // taps, rounded up to even
+    static constexpr int NW = KTP * 32;                              // weights of a plane
+    static constexpr int PPT = (NP + 64 * kWavesPerGroup - 1) / (64 * kWavesPerGroup);
+    static constexpr int WPT = (NW + 64 * kWavesPerGroup - 1) / (64 * kWavesPerGroup);
+    static constexpr size_t lds_bytes = (size_t)(2 * NP + 2 * NW + KTP) * 4;
+};
+
+template <int KS>
+__global__ void __launch_bounds__(64 * kWavesPerGroup, 2)
+context_dgrad_kernel(const float *__restrict__ gpad, const float *__restrict__ wt, float *__restrict__ out, int B, int L, int LM,
+                     int H, int W, int WpG, size_t gplane, int strips_per_row)
+{
+    using Cfg = DgCfg<KS>;
+    constexpr int NT = 64 * kWavesPerGroup;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *patch = lds;                                  // [2][NP]
+    float *wl = lds + 2 * Cfg::NP;                       // [2][NW]
+    int *toff = reinterpret_cast<int *>(lds + 2 * Cfg::NP + 2 * Cfg::NW);   // [KTP] offset of a tap in the patch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    const int strip = blockIdx.x % strips_per_row;
+    const long long ry = blockIdx.x / strips_per_row;
+    const int y = (int)(ry % H), b = (int)(ry / H);
+    const int x0 = strip * kDgStrip;
+    for (int kk = tid; kk < Cfg::KTP; kk += NT) toff[kk] = kk < Cfg::KT ? (kk / KS) * Cfg::PW + kk % KS : 0;
+    float rp[Cfg::PPT], rw[Cfg::WPT];
+    const float *gb = gpad + (size_t)b * LM * gplane + (size_t)y * WpG + x0;
+    auto fetch = [&](int o) {
+        const float *src = gb + (size_t)o * gplane;
+#pragma unroll
+        for (int i = 0; i < Cfg::PPT; ++i) {
+            const int idx = tid + i * NT;
+            const int r = idx / Cfg::PW, c = idx - r * Cfg::PW;
+            // (columns past the plane's pitch belong to pixels past the image row: zero)
+            rp[i] = (idx < Cfg::NP && x0 + c < WpG) ? src[(size_t)r * WpG + c] : 0.f;
+        }
+        const float *wsrc = wt + (size_t)o * Cfg::KT * 32;
+#pragma unroll
+        for (int i = 0; i < Cfg::WPT; ++i) {
+            const int idx = tid + i * NT;
+            rw[i] = idx < Cfg::KT * 32 ? wsrc[idx] : 0.f;
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < Cfg::PPT; ++i) {
+            const int idx = tid + i * NT;
+            if (idx < Cfg::NP) patch[buf * Cfg::NP + idx] = rp[i];
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::WPT; ++i) {
+            const int idx = tid + i * NT;
+            if (idx < Cfg::NW) wl[buf * Cfg::NW + idx] = rw[i];
+        }
+    };
+    f16v d[kDgTilesPerWave];
+#pragma unroll
+    for (int tt = 0; tt < kDgTilesPerWave; ++tt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) d[tt][v] = 0.f;
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    const int px = wave * kDgTilesPerWave * 32 + p;      // the lane's pixel of tile 0 within the strip
+    for (int o = 0; o < LM; ++o) {
+        // (the last pass fetches and stages its own plane again rather than branch: nothing reads that stage)
+        fetch(o + 1 < LM ? o + 1 : o);
+        const float *pb = patch + (o & 1) * Cfg::NP + px;
+        const float *wb = wl + (o & 1) * Cfg::NW + p;
+#pragma unroll 2
+        for (int j = 0; j < Cfg::KTP / 2; ++j) {
+            const int kk = 2 * j + h;
+            const float a = wb[kk * 32];
+            const float *row = pb + toff[kk];
+#pragma unroll
+            for (int tt = 0; tt < kDgTilesPerWave; ++tt) d[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, row[tt * 32], d[tt], 0, 0, 0);
+        }
+        stage((o + 1) & 1);
+        __syncthreads();
+    }
+    // register v of lane (p, h): label 8 (v/4) + 4 h + v%4 of the lane's pixel
+#pragma unroll
+    for (int tt = 0; tt < kDgTilesPerWave; ++tt) {
+        const int x = x0 + px + tt * 32;
+        if (x >= W) continue;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int l = 8 * (v / 4) + 4 * h + (v % 4);
+            if (l < L) out[(((size_t)b * L + l) * H + y) * W + x] = d[tt][v];
+        }
+    }
+}
+
+template <int KS>
+int launch_dgrad(const float *gpad, const float *wt, float *out, int B, int L, int LM, int H, int W, int WpG, size_t gplane, hipStream_t st)
+{
+    const int strips = (W + kDgStrip - 1) / kDgStrip;
+    const long long blocks = (long long)B * H * strips;
+    if (blocks >= (1LL << 31)) return MFL_ERR_TOO_LARGE;
+    MFL_CHECK_HIP(hipFuncSetAttribute((const void *)context_dgrad_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(context_dgrad_kernel<KS>, dim3((unsigned)blocks), dim3(64 * kWavesPerGroup), DgCfg<KS>::lds_bytes, st, gpad, wt, out, B,
+                       L, LM, H, W, WpG, gplane, strips);
+    return (int)hipGetLastError();
 }
 
 // d t = la_w * d a;  d la_w = sum_b d a * t;  d la_b = sum_b d a  (LinearActivation, AdvancedModel.py:52-56).  One thread per
@@ -665,7 +766,7 @@ struct ContextWorkspace {
     size_t apad, w2, koff, total;
     int Hp, Wp, KK, KKp;
     // backward only
-    size_t logq, amin, cmin, gpad, wt, koff2, da, part;
+    size_t logq, amin, cmin, gpad, wt, da, part;
     int HpG, WpG, KK2, KK2p, ncb, nsl, tiles_per_slice;
 };
 
@@ -694,7 +795,6 @@ ContextWorkspace context_carve(int B, int L, int M, int H, int W, int ks, bool b
         w.KK2 = L * M * ks * ks;
         w.KK2p = (w.KK2 + kChunk - 1) / kChunk * kChunk;
         w.wt = take((size_t)w.KK2p * 32 * 4);
-        w.koff2 = take((size_t)w.KK2p * 4);
         w.da = take(n * 4);
         w.ncb = w.KKp / 32;
         const long long ntiles = (long long)B * H * ((W + 63) / 64);
@@ -711,7 +811,7 @@ ContextWorkspace context_carve(int B, int L, int M, int H, int W, int ks, bool b
 
 bool context_supported(int L, int M, int ks) { return L >= 1 && L <= 32 && M >= 1 && M <= 5 && ks >= 1 && ks <= 15 && (ks & 1); }
 
-// Launch of the implicit-GEMM kernel: the forward (MODE 0) or a plain convolution into `smooth` (MODE 1, M = 1).
+// Launch of the implicit-GEMM kernel of the forward (MODE 0: rows 32 m + l; MODE 2: packed rows).
 template <int M, int MODE>
 int launch(const float *planes, const float *w2, const int *koff, int KKp, int Cin, int Wp, int plane, const float *conv_b,
            const float *ga_w, const float *ga_b, const float *unary, float *smooth, float *logq, unsigned char *amin, float *cmin,
@@ -719,7 +819,6 @@ int launch(const float *planes, const float *w2, const int *koff, int KKp, int C
 {
     const int tiles_per_row = (W + 31) / 32;
     const long long ntiles = (long long)B * H * tiles_per_row;
-    constexpr int kTilesPerWave = TilesPerWave<MODE>::value;
     long long groups = (ntiles + kWavesPerGroup * kTilesPerWave - 1) / (kWavesPerGroup * kTilesPerWave);
     groups = (groups + 7) / 8 * 8;                      // (the kernel deals contiguous ranges to the 8 XCDs)
     if (groups >= (1LL << 31)) return MFL_ERR_TOO_LARGE;
@@ -929,10 +1028,17 @@ int context_backward(const float *t, const float *la_w, const float *la_b, const
     {
         const size_t nw = (size_t)ws.KK2p * 32;
         hipLaunchKernelGGL(context_dgrad_weights_kernel, dim3((unsigned)((nw + 255) / 256 < 65535u ? (nw + 255) / 256 : 65535u)), dim3(256), 0, st,
-                           conv_w, (float *)(base + ws.wt), (int *)(base + ws.koff2), L, LM, ks, ws.KK2, ws.KK2p, (int)gplane, ws.WpG);
+                           conv_w, (float *)(base + ws.wt), L, LM, ks, ws.KK2, ws.KK2p);
         MFL_CHECK_HIP(hipGetLastError());
-        rc = launch<1, 1>(gpad, (const float *)(base + ws.wt), (const int *)(base + ws.koff2), ws.KK2p, LM, ws.WpG, (int)gplane, nullptr,
-                          nullptr, nullptr, nullptr, la_w ? da : d_t, nullptr, nullptr, nullptr, B, L, H, W, st);
+        const float *wtp = (const float *)(base + ws.wt);
+        float *dout = la_w ? da : d_t;
+#define MFL_CTX_DGRAD(KSV) case KSV: rc = launch_dgrad<KSV>(gpad, wtp, dout, B, L, LM, H, W, ws.WpG, gplane, st); break;
+        switch (ks) {
+            MFL_CTX_DGRAD(1) MFL_CTX_DGRAD(3) MFL_CTX_DGRAD(5) MFL_CTX_DGRAD(7) MFL_CTX_DGRAD(9) MFL_CTX_DGRAD(11) MFL_CTX_DGRAD(13)
+            MFL_CTX_DGRAD(15)
+        default: rc = MFL_ERR_INVALID_ARGUMENT;
+        }
+#undef MFL_CTX_DGRAD
         if (rc) return rc;
         if (la_w) {
             const size_t LHW = (size_t)L * HW;
