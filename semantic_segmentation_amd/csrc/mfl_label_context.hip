@@ -146,13 +146,20 @@ label_context_kernel(const float *__restrict__ apad, const float *__restrict__ w
         pixl[tt] = y * W + xc;
         base[tt] = b * Cin * plane + y * Wp + xc;            // window origin of the pixel in the padded planes
     }
+    // The accumulators start at the convolution's bias (register v of block m of lane (p, h) is row 32 m + 8 (v/4) + 4 h +
+    // v%4: output channel m*L + l, or the row itself with packed rows), so the epilogue has no bias to fetch.
     f16v d[kTilesPerWave][M];
 #pragma unroll
-    for (int tt = 0; tt < kTilesPerWave; ++tt)
+    for (int m = 0; m < M; ++m)
 #pragma unroll
-        for (int m = 0; m < M; ++m)
+        for (int v = 0; v < 16; ++v) {
+            const int l = 8 * (v / 4) + 4 * h + (v % 4);
+            const int oc = MODE == 2 ? 32 * m + l : m * L + l;
+            const bool row = MODE == 2 ? oc < L * mixtures : l < L;
+            const float bias = (conv_b && row) ? conv_b[oc] : 0.f;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) d[tt][m][v] = 0.f;
+            for (int tt = 0; tt < kTilesPerWave; ++tt) d[tt][m][v] = bias;
+        }
 
     // Software pipeline: the weights of chunk c + 1 travel global -> registers while chunk c is multiplied and reach
     // the other LDS stage after it (one barrier per chunk); the activations of group g + 1 (kAhead k-steps) are
@@ -270,7 +277,7 @@ label_context_kernel(const float *__restrict__ apad, const float *__restrict__ w
                 for (int m = 0; m < kMaxMixtures; ++m) {
                     const int mc = m < mixtures ? m : mixtures - 1;
                     const int oc = mc * L + lc;
-                    const float cv = tile[oc * 32 + p] + (conv_b ? conv_b[oc] : 0.f);
+                    const float cv = tile[oc * 32 + p];
                     float c = cv;
                     if (ga_w) c = fmaf(ga_w[(size_t)oc * HW + l0], c, ga_b[(size_t)oc * HW + l0]);
                     // (mixtures arrive in increasing m: the first minimum wins, as torch.min(dim))
@@ -301,7 +308,7 @@ label_context_kernel(const float *__restrict__ apad, const float *__restrict__ w
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 const int oc = m * L + lc;
-                const float cv = d[tt][m][v] + (conv_b ? conv_b[oc] : 0.f);
+                const float cv = d[tt][m][v];
                 float c = cv;
                 if (ga_w) c = fmaf(ga_w[(size_t)oc * HW + l0], c, ga_b[(size_t)oc * HW + l0]);
                 if (m == 0 || c < mn) { mn = c; m_at = m; cv_at = cv; }      // (the first minimum, as torch.min(dim))
